@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors from the IMPORTED reference helpers.
+
+Runs only in the authoring container (needs /root/reference); the GPU box and the
+test-suite only read the resulting ``*.npz`` files (plain uint8/int/f32 arrays,
+loaded with allow_pickle=False).
+
+What is imported from the reference (numpy half of the path, importable here):
+  src/util.py        generatePerspective, generatePerspectiveOptimized,
+                     rotate_state, shift_state
+  src/util_actor.py  generateTransitionParallel, selectActionParallel_prime
+The only shim is restoring the numpy-1 aliases np.int/np.bool/np.float that
+numpy 2 removed (src/util.py:10 uses np.int).  ``src/numba/*`` needs numba, which
+is absent here and stays absent: those files restate src/util.py (the reference's
+own tests/time_test_genPersp.py checks exactly that equivalence) and are read as
+text only.
+
+The gym_ToricCode env (reset/step/syndrome) is not in the reference tree, so no
+vector for it can be generated from the reference: env_kat_d*.npz below holds
+DERIVED known answers (single-Pauli syndromes per the adjacency rule of
+util.py:68-69,77-78 and the facts SURVEY.md 8(c) records about fixture rows
+0/2/7/13/19 of output_speed_test/transitions_0.npy: Z on the centred qubit flips
+vertex (gs,gs) and (gs+1,gs) in both layers' perspectives).  That file itself is
+a pickled object array; numpy.load(allow_pickle=False) refuses it and it is not
+unpickled here.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("TORIC_REFERENCE", "/root/reference")
+
+np.int = int      # numpy-1 aliases used by the reference (src/util.py:10)
+np.bool = bool
+np.float = float
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import src.util as RU            # noqa: E402  (reference)
+import src.util_actor as RA      # noqa: E402  (reference)
+from oracle import toric_oracle as O  # noqa: E402
+
+
+def random_states(rng, d, k):
+    """Mix of realistic syndromes (from the oracle sampler at several p) and
+    adversarial binary grids (empty, full, single cell, dense random)."""
+    out = []
+    for p in (0.02, 0.1, 0.15, 0.3):
+        _, st = O.reset_lattices(int(rng.integers(1 << 30)), np.arange(k), 0, p, d)
+        out.append(st)
+    dense = (rng.random((k, 2, d, d)) < 0.5).astype(np.uint8)
+    out.append(dense)
+    special = np.zeros((4 + 2 * d * d, 2, d, d), np.uint8)
+    special[1] = 1
+    special[2, 0, 0, 0] = 1
+    special[3, 1, d - 1, d - 1] = 1
+    for c in range(2 * d * d):
+        special[4 + c].reshape(-1)[c] = 1
+    out.append(special)
+    return np.concatenate(out, axis=0)
+
+
+def ref_perspectives(d, states):
+    gs = int(d / 2)
+    pers, poss, counts = [], [], []
+    for s in states:
+        s64 = s.astype(np.int64)
+        a, b = RU.generatePerspectiveOptimized(gs, d, s64)
+        loop = RU.generatePerspective(gs, d, s64)          # authoritative loop form
+        assert len(loop) == len(a)
+        for x, y, z in zip(loop, a, b):
+            assert np.array_equal(x.perspective, y) and tuple(int(t) for t in x.position) == tuple(int(t) for t in z)
+        pers.extend(a)
+        poss.extend(b)
+        counts.append(len(a))
+    P = len(pers)
+    return (np.asarray(pers, np.int64).reshape(P, 2, d, d),
+            np.asarray(poss, np.int64).reshape(P, 3), np.asarray(counts, np.int64))
+
+
+def main():
+    rng = np.random.default_rng(20200318)
+    report = []
+    for d in (3, 5, 7, 9):
+        gs = int(d / 2)
+        k = {3: 40, 5: 30, 7: 24, 9: 16}[d]
+        states = random_states(rng, d, k)
+        n = states.shape[0]
+
+        # --- perspectives: reference vs oracle (both forms), then freeze
+        rp, rpos, rcnt = ref_perspectives(d, states)
+        op, opos, ocnt = O.generate_perspective_batch_ref(gs, d, states.astype(np.int64))
+        bp, bpos, bcnt, boff = O.generate_perspective_batch(states)
+        assert np.array_equal(rp, op) and np.array_equal(rpos, opos) and np.array_equal(rcnt, ocnt)
+        assert np.array_equal(rp, bp) and np.array_equal(rpos, bpos) and np.array_equal(rcnt, bcnt)
+
+        # --- rotate / shift KATs
+        ar = np.arange(2 * d * d).reshape(2, d, d)
+        rot = RU.rotate_state(ar)
+        assert np.array_equal(rot, O.rotate_state_ref(ar))
+        sh_a, sh_b = RU.shift_state(1, d - 1, ar, ar[::-1].copy(), gs)
+        oa, ob = O.shift_state_ref(1, d - 1, ar, ar[::-1].copy(), gs)
+        assert np.array_equal(sh_a, oa) and np.array_equal(sh_b, ob)
+
+        # --- transitions: random (state,next_state) pairs + random legal actions
+        nxt = states[rng.permutation(n)]
+        actions = np.stack((rng.integers(0, 2, n), rng.integers(0, d, n),
+                            rng.integers(0, d, n), rng.integers(1, 4, n)), axis=1).astype(np.int64)
+        reward = rng.integers(-4, 5, n).astype(np.float64)
+        terminal = rng.random(n) < 0.2
+        trans_type = np.dtype([('perspective', (np.int64, (2, d, d))),
+                               ('action', RU.action_type), ('reward', np.float64),
+                               ('next_perspective', (np.int64, (2, d, d))),
+                               ('terminal', np.bool_)])   # Actor_mp.py:52-56
+        rt = RA.generateTransitionParallel(actions, reward, states.astype(np.int64),
+                                           nxt.astype(np.int64), terminal, gs, trans_type)
+        ot = O.generate_transition_ref(actions, reward, states.astype(np.int64),
+                                       nxt.astype(np.int64), terminal, gs)
+        bper, bact, bnper = O.generate_transition_batch(actions, states, nxt)
+        assert np.array_equal(rt['perspective'], ot['perspective'])
+        assert np.array_equal(rt['next_perspective'], ot['next_perspective'])
+        assert np.array_equal(rt['action']['position'], ot['position'])
+        assert np.array_equal(rt['action']['op'], ot['op'])
+        assert np.array_equal(rt['perspective'], bper) and np.array_equal(rt['next_perspective'], bnper)
+        assert np.array_equal(rt['action']['position'], bact[:, :3]) and np.array_equal(rt['action']['op'], bact[:, 3])
+        assert np.array_equal(rt['reward'], reward) and np.array_equal(rt['terminal'], terminal)
+
+        # --- greedy selection (reference branch without RNG): util_actor.py:189-221
+        q = rng.standard_normal((rp.shape[0], 3)).astype(np.float32)
+        q[rng.integers(0, q.shape[0], 8)] = q.max()           # force ties
+        nz = rcnt > 0                                           # reference cannot select on an empty slice
+        offs = np.zeros(n + 1, np.int64)
+        np.cumsum(rcnt, out=offs[1:])
+        qs = [q[offs[i]:offs[i + 1]] for i in range(n) if nz[i]]
+        ps = [rpos[offs[i]:offs[i + 1]] for i in range(n) if nz[i]]
+        ract, rqv = RA.selectActionParallel_prime(qs, ps, np.ones(len(qs), bool))
+        oact, oqv, _ = O.select_action_batch(q, offs, rpos, 0.0, 1, np.arange(n), 1, 0)
+        assert np.array_equal(ract, oact[nz]) and np.array_equal(rqv.astype(np.float32), oqv[nz])
+
+        np.savez_compressed(
+            os.path.join(HERE, f"reference_d{d}.npz"),
+            states=states.astype(np.uint8), perspectives=rp.astype(np.uint8),
+            positions=rpos.astype(np.uint8), counts=rcnt.astype(np.int32),
+            rotate_in=ar.astype(np.int16), rotate_out=rot.astype(np.int16),
+            shift_prev=sh_a.astype(np.int16), shift_next=sh_b.astype(np.int16),
+            t_next_states=nxt.astype(np.uint8), t_actions=actions.astype(np.uint8),
+            t_reward=reward, t_terminal=terminal,
+            t_perspective=rt['perspective'].astype(np.uint8),
+            t_next_perspective=rt['next_perspective'].astype(np.uint8),
+            t_position=rt['action']['position'].astype(np.uint8), t_op=rt['action']['op'].astype(np.uint8),
+            sel_q=q, sel_nonempty=nz, sel_actions=ract.astype(np.uint8), sel_qv=rqv.astype(np.float32))
+        report.append((d, n, int(rp.shape[0])))
+
+    # --- roll KAT of tests/roll_numba.py:36-56 (np.roll on arange(162).reshape(2,9,9))
+    b = np.arange(162).reshape(2, 9, 9)
+    np.savez_compressed(os.path.join(HERE, "roll_kat.npz"), b=b.astype(np.int16),
+                        roll_axis1_p1=np.roll(b, 1, axis=1).astype(np.int16),
+                        roll_axis2_m1=np.roll(b, -1, axis=2).astype(np.int16))
+
+    # --- hand-made d=5 qubit matrix of tests/plotSyndroms.py:10-20 (input only upstream)
+    s = np.zeros((2, 5, 5), np.uint8)
+    s[0, 2, 2] = s[0, 3, 2] = 3
+    s[1, 1, 0] = s[1, 1, 1] = 3
+    np.savez_compressed(os.path.join(HERE, "plot_syndroms_d5.npz"), qubits=s)
+
+    for d, n, P in report:
+        print(f"d={d}: {n} states, {P} perspectives frozen; reference == oracle_ref == oracle_batch")
+
+
+if __name__ == "__main__":
+    main()

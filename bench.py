@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the toric-code env hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of lattices, in the call order of the
+reference's actor loop (src/Actor_mp.py:104-185) with the policy network left out (it is stock
+torch conv work, out of scope; epsilon starts at 1 upstream, Actor_mp.py:37, where the Q-values
+never influence the action):
+
+    perspective counts -> exclusive scan -> perspective stack write (P,2,d,d) f32 + positions
+    -> eps=1 selection, env step, transition record, auto-reset, next counts (one fused kernel)
+
+Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on:
+65 536 lattices, d=7, p_error=0.10.  Inputs are resident in HBM when the timed region starts
+(the lattices live on the device; nothing crosses PCIe in the loop).
+
+N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns a contiguous block of
+global env ids (weak scaling: 65 536 lattices per GPU); the only exchange is the gather of packed
+transition blocks to rank 0's HBM replay ring (RCCL over xGMI) every --flush steps, issued async
+so it overlaps the next steps.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (perspective
+write kernel, HIP events around every launch in the timed region) and `cpu_baseline` (the C
+oracle's actor loop on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=65536, help="lattices per GPU")
+    ap.add_argument("--size", type=int, default=7)
+    ap.add_argument("--p-error", type=float, default=0.10)
+    ap.add_argument("--seed", type=int, default=2020)
+    ap.add_argument("--out-dtype", default="f32", choices=["f32", "f16", "bf16", "u8"])
+    ap.add_argument("--flush", type=int, default=8, help="steps per transition block / gather (N>1)")
+    ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
+    return ap.parse_args()
+
+
+def cpu_baseline(d, p, seed, budget_s):
+    """The oracle's C actor loop (EnvSet.step + generatePerspectiveBatch + generateTransitionParallel
+    restated, oracle/toric_oracle.c) timed on the host cores: bounded sample of the same workload."""
+    from oracle.c_oracle import CEnvBatch, lib
+    L = lib()
+    threads = L.tor_num_threads()
+    n = 4096
+    env = CEnvBatch(d, n, p, seed=seed)
+    env.reset()
+    t0 = time.perf_counter()
+    env.actor_steps(2)
+    probe = (time.perf_counter() - t0) / 2
+    steps = int(max(4, min(2000, budget_s / max(probe, 1e-6))))
+    t0 = time.perf_counter()
+    P, _ = env.actor_steps(steps)
+    dt = time.perf_counter() - t0
+    out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
+           "sample": f"{n} lattices x {steps} steps, d={d}, p={p}, C oracle actor loop (OpenMP, {threads} threads), {dt:.1f} s",
+           "perspectives_per_sec": P / dt}
+    # the same loop in the reference's own shape (per-lattice python + np.roll), tiny sample
+    from oracle import toric_oracle as O
+    oe = O.OracleEnvSet(d, 64, p, seed=seed)
+    oe.resetAll()
+    t0 = time.perf_counter()
+    O.run_actor_steps_ref(oe, 4, eps=1.0)
+    out["numpy_reference_shaped_steps_per_sec"] = 64 * 4 / (time.perf_counter() - t0)
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    import torch.distributed as dist
+    import toric_rl_decoder_amd as T
+    from toric_rl_decoder_amd import gather as G
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    d, n, K, W = args.size, args.envs, args.steps, args.warmup
+    nq = 2 * d * d
+    tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "u8": torch.uint8}[args.out_dtype]
+    esize = {"f32": 4, "f16": 2, "bf16": 2, "u8": 1}[args.out_dtype]
+
+    env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": 0, "p_error": args.p_error})
+    first, _ = G.shard_range(n * world, world, rank)
+    envs = T.EnvSet(env, n, device=device, seed=args.seed, first_env_id=first, numpy_io=False)
+    envs.resetAll()
+
+    # worst case every qubit is a hit (random exploration grows the defect density): size the stack
+    # for that -- 2.5 GB at d=7 f32, 6.9 GB at d=9 -- out of 288 GB of HBM
+    cap = n * nq
+    stack = torch.empty((cap, 2, d, d), dtype=tdtype, device=device)
+    positions = torch.empty((cap, 3), dtype=torch.int32, device=device)
+    p_log = torch.zeros(W + K, dtype=torch.int64, device=device)
+
+    flush = max(1, args.flush)
+    blocks = None if args.no_transitions else [envs.newTransitionBlock(steps=flush) for _ in range(2)]
+    tg = None
+    if world > 1 and blocks is not None:
+        tg = G.TransitionGather(blocks[0].nbytes, device, ring_slots=2)
+
+    use_events = not args.no_events
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if use_events else []
+
+    def one_step(t, timed_idx=None):
+        _, off = envs.perspectiveCounts()
+        if timed_idx is not None and use_events:
+            ev[timed_idx][0].record()
+        envs.writePerspectives(stack, positions, off)
+        if timed_idx is not None and use_events:
+            ev[timed_idx][1].record()
+        p_log[t:t + 1].copy_(off[-1:])
+        blk = None if blocks is None else blocks[(t // flush) & 1]
+        envs.actorStep(None, block=blk, slot=t % flush, want_actions=True)
+        if tg is not None and (t + 1) % flush == 0:
+            tg.gather(blk.buf)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for t in range(W):
+        one_step(t)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        one_step(W + k, k)
+    if tg is not None:
+        tg.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    envs.check()                                                  # capacity / action latch
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    p_timed = p_log[W:].to(torch.float64)
+    p_sum = p_timed.sum().reshape(1)
+    if world > 1:
+        dist.all_reduce(p_sum, op=dist.ReduceOp.SUM)
+    total_steps = float(n) * world * K
+
+    if rank == 0:
+        res = {
+            "metric": "env steps/sec (batched) at d=%d p=%g" % (d, args.p_error),
+            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d lattices/GPU, d=%d, p_error=%g; actor-loop pass = "
+                                   "perspective stack (%s) + positions -> eps=1 selection -> step -> transition "
+                                   "record -> auto-reset (max 75 steps/episode); policy NN excluded" %
+                                   (n, d, args.p_error, args.out_dtype),
+                       "envs_per_gpu": n, "d": d, "p_error": args.p_error, "out_dtype": args.out_dtype,
+                       "transitions": blocks is not None, "flush_steps": flush, "parallelism": "env-shard x%d" % world},
+            "perspectives_per_sec": float(p_sum.item()) / elapsed,
+        }
+        if use_events:
+            ms = np.array([a.elapsed_time(b) for a, b in ev])
+            p_mean = float(p_timed.mean().item())
+            alg = p_mean * (nq * esize + 12) + n * nq                  # P*(B_p+12) + N*2d^2
+            achieved = alg / (ms.mean() * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    j = json.load(open(pmc))
+                    if j.get("envs") == n and j.get("d") == d and j.get("out_dtype") == args.out_dtype:
+                        traffic = j.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "hbm", "kernel": "k_persp_write", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                               "bytes_per_launch": alg, "avg_launch_ms": float(ms.mean()),
+                               "median_launch_ms": float(np.median(ms)), "perspectives_per_launch": p_mean}
+        if world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(d, args.p_error, args.seed, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    envs.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,174 @@
+/*
+ * libtoricenv -- C-ABI of the MI355X-native batched toric-code environment.
+ *
+ * This is the drop-in boundary for the reference's env hot path.  The reference has no
+ * FFI of its own (pure Python duck typing); each entry point below names the Python
+ * interface it replaces (paths relative to the upstream tree).  A reference-side ctypes
+ * binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (TQ_E_*); tq_last_error() gives
+ *    the message of the calling thread's last failure.  Nothing aborts.
+ *  - all array arguments are DEVICE pointers owned by the caller (e.g. a PyTorch-ROCm
+ *    tensor's data_ptr()) unless the name says "host".  The library owns only the
+ *    per-handle lattice state.  No allocation and no synchronisation happens on the hot
+ *    path: kernels are enqueued on `stream` (a hipStream_t, NULL = default stream) and
+ *    the call returns.
+ *  - lattices are (2,d,d): [0] = vertex matrix, [1] = plaquette matrix (src/util.py:63-64);
+ *    qubit codes I=0 X=1 Y=2 Z=3 (docs/toric_model.md:11); action = [layer,row,col,op],
+ *    op in 1..3 (src/util.py:10, src/numba/util_actor.py:100-104).
+ *  - a handle is not thread-safe; use one handle per process / GPU
+ *    (one actor process per device: Distributed_mp.py:201-211).
+ *  - RNG: counter-based Philox4x32-10 keyed (seed, global env id, episode, round/step);
+ *    contract in DESIGN.md.  Results are identical for any partition of env ids over GPUs.
+ */
+#ifndef TORICENV_H
+#define TORICENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TQ_VERSION 100
+
+#define TQ_OK 0
+#define TQ_E_INVALID (-1)   /* bad argument (NULL handle, even d, unsupported d, n <= 0 ...) */
+#define TQ_E_HIP (-2)       /* a HIP runtime call failed; message in tq_last_error() */
+#define TQ_E_CAPACITY (-3)  /* output capacity too small */
+#define TQ_E_ACTION (-4)    /* an action outside the lattice / op not in 1..3 was seen on the device */
+
+/* element type of the perspective stack written by tq_persp_write */
+#define TQ_F32 0            /* float32 -- what the reference feeds the NN (numba/util_actor.py:39) */
+#define TQ_F16 1
+#define TQ_BF16 2
+#define TQ_U8 3
+
+/* p_error strategy of the fused auto-reset (Actor_mp.py:176-180) */
+#define TQ_PERR_FIXED 0     /* every reset uses p_error_default */
+#define TQ_PERR_LINEAR 1    /* roof = min(final, roof + delta); p = roof */
+#define TQ_PERR_RANDOM 2    /* roof as above; p ~ U(start, roof) */
+
+typedef struct tq_env tq_env;
+
+int tq_version(void);
+const char* tq_last_error(void);
+
+/* gym.make('toric-code-v0', config={"size","min_qubit_errors":0,"p_error"}) + EnvSet(env, no_envs)
+ * (Distributed_mp.py:72-76, src/EnvSet.py:5-16).  d odd in {3,5,7,9,11}.  Lattice e of this
+ * handle has global env id first_env_id + e (shard offset for multi-GPU). */
+int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_t first_env_id);
+int tq_destroy(tq_env* h);
+
+/* env config: default p_error (gym config "p_error"), terminal reward (default 100,
+ * evaluation.py:175), max_actions_per_episode (default 75, Distributed_mp.py:44; used only by
+ * tq_actor_step's auto-reset). */
+int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int max_steps_per_episode);
+/* p_error schedule of the actor's reset policy (Actor_mp.py:41-46,176-180) for tq_actor_step. */
+int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_final, double p_delta);
+
+int tq_num_envs(const tq_env* h);
+int tq_size(const tq_env* h);
+
+/* EnvSet.resetAll(p_errors) (EnvSet.py:29-36): p_err = device f64[N] or NULL (default p). */
+int tq_reset_all(tq_env* h, const double* p_err, void* stream);
+/* EnvSet.resetTerminalEnvs(idx, p_errors) (EnvSet.py:19-27): idx = device i32[n_idx] (distinct),
+ * p_err = device f64[n_idx] or NULL. */
+int tq_reset_idx(tq_env* h, const int32_t* idx, int n_idx, const double* p_err, void* stream);
+
+/* EnvSet.step(actions) (EnvSet.py:38-47): actions = device i32[N,4]; rewards f32[N];
+ * terminals u8[N].  No auto-reset (the caller resets, Actor_mp.py:171-183).  The pre-step
+ * syndrome is kept inside the handle for tq_transition_write. */
+int tq_step(tq_env* h, const int32_t* actions, float* rewards, uint8_t* terminals, void* stream);
+
+/* env.state / EnvSet.states: syndrome as u8[N,2,d,d] (0/1). */
+int tq_get_state(tq_env* h, uint8_t* out, void* stream);
+/* rows idx[0..n_idx) only -> u8[n_idx,2,d,d] (return value of resetTerminalEnvs). */
+int tq_get_state_idx(tq_env* h, const int32_t* idx, int n_idx, uint8_t* out, void* stream);
+/* env.qubit_matrix as u8[N,2,d,d] Pauli codes. */
+int tq_get_qubits(tq_env* h, uint8_t* out, void* stream);
+/* overwrite env.qubit_matrix and recompute env.state = createSyndromOpt(qubit_matrix)
+ * (results/small_p_error_test.py:112-120, results/start_from_state.py:34-38). */
+int tq_set_qubits(tq_env* h, const uint8_t* qubits, void* stream);
+/* per-lattice counters: episodes started, steps taken in the current episode (u32[N] each). */
+int tq_get_counters(tq_env* h, uint32_t* episodes, uint32_t* steps, void* stream);
+/* env.evalGroundState() per lattice -> u8[N] (1 = no non-trivial loop). */
+int tq_eval_ground_state(tq_env* h, uint8_t* out, void* stream);
+/* env.isTerminalState(state) per lattice -> u8[N]. */
+int tq_is_terminal(tq_env* h, uint8_t* out, void* stream);
+
+/* generatePerspectiveBatch, step 1 (numba/util_actor.py:56-67 + cumsum :35): counts i32[N]
+ * (may be NULL) and offsets i64[N+1] (exclusive scan, offsets[N] = P). */
+int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream);
+/* generatePerspectiveBatch + np.concatenate, step 2 (numba/util_actor.py:33-39): writes the
+ * env-major stack out[P,2,d,d] of element type `dtype` and positions i32[P,3] (may be NULL)
+ * for the offsets from tq_persp_count.  capacity = number of perspectives `out` can hold;
+ * lattices that would overflow it are skipped and TQ_E_CAPACITY is latched (tq_check). */
+int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positions,
+                   int64_t capacity, int dtype, void* stream);
+
+/* Same two steps for a batch of syndromes that does not live in a handle (the learner's
+ * predictMaxOptimized, util_learner.py:48-111): states = device u8[n,2,d,d]. */
+int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, int64_t* offsets,
+                          void* stream);
+int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* offsets, void* out,
+                          int32_t* positions, int64_t capacity, int dtype, void* stream);
+
+/* _selectActionBatch_prime (numba/util_actor.py:69-107) on the device: q_table f32[P,3],
+ * offsets i64[N+1], positions i32[P,3], eps f64[N] -> actions i32[N,4], q_values f32[N,3].
+ * greedy iff (1-eps) > U; greedy = first maximum in row-major order; otherwise a uniform
+ * perspective and op (Philox, keyed by the lattice's episode and step counters).
+ * q_table may be NULL when every eps is 1 (pure exploration: the Q-values are never read). */
+int tq_select_action(tq_env* h, const float* q_table, const int64_t* offsets,
+                     const int32_t* positions, const double* eps, int32_t* actions,
+                     float* q_values, void* stream);
+
+/* generateTransitionParallel (util_actor.py:223-264) for the last tq_step: perspective of the
+ * pre-step and post-step syndrome centred on the acted qubit (rotated for layer 1), action
+ * rewritten to (layer, gs, gs, op).  Outputs (any may be NULL): persp u8[N,2,d,d],
+ * next_persp u8[N,2,d,d], actions_out i32[N,4]. */
+int tq_transition_write(tq_env* h, const int32_t* actions, uint8_t* persp, uint8_t* next_persp,
+                        int32_t* actions_out, void* stream);
+
+/* generateTransitionParallel(action, reward, state, next_state, terminal, grid_shift, type)
+ * (util_actor.py:223-264) for explicit syndrome arrays that do not live in a handle:
+ * states / next_states = device u8[n,2,d,d], actions = device i32[n,4]
+ * -> persp u8[n,2,d,d], next_persp u8[n,2,d,d], actions_out i32[n,4] (any may be NULL). */
+int tq_states_transition(int d, int n, const uint8_t* states, const uint8_t* next_states,
+                         const int32_t* actions, uint8_t* persp, uint8_t* next_persp,
+                         int32_t* actions_out, void* stream);
+
+/* Packed transition block (the wire format gathered to the replay memory): for `cap`
+ * transitions, SoA sections in this order, each 8-byte aligned:
+ *   persp_v u64[W][cap] | persp_p u64[W][cap] | next_v u64[W][cap] | next_p u64[W][cap] |
+ *   action u32[cap] (layer | row<<8 | col<<16 | op<<24) | reward f32[cap] | terminal u8[cap]
+ * with W = ceil(d*d/64) and bit r*d+c of a plane = cell (r,c). */
+int64_t tq_transition_block_bytes(int d, int64_t cap);
+/* unpack slots [first, first+count) of a block into u8 grids / i32 actions / f32 rewards /
+ * u8 terminals (any output may be NULL). */
+int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, int64_t count,
+                         uint8_t* persp, uint8_t* next_persp, int32_t* actions, float* rewards,
+                         uint8_t* terminals, void* stream);
+
+/* One fused iteration of the actor loop body after the policy (Actor_mp.py:116-183):
+ *   step (EnvSet.step) -> transition record (generateTransitionParallel) -> reset of terminal
+ *   / timed-out lattices with the p_error schedule (resetTerminalEnvs) -> perspective counts
+ *   of the resulting states.
+ * actions: device i32[N,4] from tq_select_action / the caller, or NULL = pure exploration
+ * (eps = 1: uniform random perspective and op drawn in-kernel with the same Philox draws as
+ * tq_select_action).  Outputs (may be NULL): actions_out i32[N,4] (the actions taken),
+ * rewards f32[N], terminals u8[N], block/slot: packed transition block with capacity
+ * `block_cap` transitions, lattice e writing slot `slot_base + e`. */
+int tq_actor_step(tq_env* h, const int32_t* actions, int32_t* actions_out, float* rewards,
+                  uint8_t* terminals, void* block, int64_t block_cap, int64_t slot_base,
+                  void* stream);
+
+/* Reads and clears the handle's device error latch (synchronises `stream`): 0, TQ_E_ACTION
+ * or TQ_E_CAPACITY. */
+int tq_check(tq_env* h, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORICENV_H */

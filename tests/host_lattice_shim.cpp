@@ -1,0 +1,158 @@
+// Host-side instantiation of the product's bit-plane header (csrc/lattice.hpp) so its
+// algebra can be unit-tested against the oracle on a machine without a GPU.
+// TEST ONLY: built by tests/test_lattice_host.py into a temp dir with g++; it is not a
+// backend of the product (the product's only compute path is the HIP library).
+#include <stdint.h>
+#include <string.h>
+
+#include "lattice.hpp"
+
+using namespace tq;
+
+template <int D>
+static void pack_qubits(const uint8_t* q, typename Lat<D>::State& s) {
+    using L = Lat<D>;
+    for (int l = 0; l < 2; ++l) {
+        s.x[l] = L::B::zero(); s.z[l] = L::B::zero();
+        for (int c = 0; c < L::DD; ++c) {
+            int code = q[l * L::DD + c];
+            s.x[l].flip(c, (code == 1) | (code == 2));
+            s.z[l].flip(c, (code >> 1) & 1);
+        }
+    }
+}
+template <int D>
+static void pack_state(const uint8_t* st, typename Lat<D>::B& v, typename Lat<D>::B& p) {
+    using L = Lat<D>;
+    v = L::B::zero(); p = L::B::zero();
+    for (int c = 0; c < L::DD; ++c) { v.flip(c, st[c] != 0); p.flip(c, st[L::DD + c] != 0); }
+}
+template <int D>
+static void unpack_state(const typename Lat<D>::B& v, const typename Lat<D>::B& p, uint8_t* st) {
+    using L = Lat<D>;
+    for (int c = 0; c < L::DD; ++c) { st[c] = (uint8_t)v.get(c); st[L::DD + c] = (uint8_t)p.get(c); }
+}
+template <int D>
+static void unpack_qubits(const typename Lat<D>::State& s, uint8_t* q) {
+    using L = Lat<D>;
+    for (int l = 0; l < 2; ++l)
+        for (int c = 0; c < L::DD; ++c) q[l * L::DD + c] = (uint8_t)L::code(s, l, c);
+}
+
+template <int D>
+static void t_syndrome(int n, const uint8_t* q, uint8_t* st) {
+    using L = Lat<D>;
+    for (int e = 0; e < n; ++e) {
+        typename L::State s;
+        pack_qubits<D>(q + (size_t)e * L::NQ, s);
+        L::syndrome(s);
+        unpack_state<D>(s.v, s.p, st + (size_t)e * L::NQ);
+    }
+}
+template <int D>
+static void t_counts(int n, const uint8_t* st, int32_t* counts, uint8_t* masks) {
+    using L = Lat<D>;
+    for (int e = 0; e < n; ++e) {
+        typename L::B v, p, e0, e1;
+        pack_state<D>(st + (size_t)e * L::NQ, v, p);
+        counts[e] = L::persp_count(v, p);
+        L::hit_masks(v, p, e0, e1);
+        unpack_state<D>(e0, e1, masks + (size_t)e * L::NQ);
+    }
+}
+template <int D>
+static void t_lut(int32_t* lut) {
+    using L = Lat<D>;
+    for (int layer = 0; layer < 2; ++layer)
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j)
+                for (int c = 0; c < 2; ++c)
+                    for (int r = 0; r < D; ++r)
+                        for (int s = 0; s < D; ++s)
+                            lut[((size_t)(layer * L::DD + i * D + j)) * L::NQ + c * L::DD + r * D + s] =
+                                L::persp_src(layer, i, j, c, r, s);
+}
+template <int D>
+static void t_perspective(int n, const uint8_t* st, const int32_t* act, uint8_t* out) {
+    using L = Lat<D>;
+    for (int e = 0; e < n; ++e) {
+        typename L::B v, p, ov, op;
+        pack_state<D>(st + (size_t)e * L::NQ, v, p);
+        L::perspective(v, p, act[4 * e], act[4 * e + 1], act[4 * e + 2], ov, op);
+        unpack_state<D>(ov, op, out + (size_t)e * L::NQ);
+    }
+}
+template <int D>
+static void t_reset(int n, uint64_t seed, int64_t first_env, const uint32_t* episodes, const double* p,
+                    uint8_t* q, uint8_t* st, int32_t* rounds) {
+    using L = Lat<D>;
+    for (int e = 0; e < n; ++e) {
+        typename L::State s;
+        rounds[e] = reset_lattice<D>(s, seed, (uint32_t)(first_env + e), episodes[e], p[e]);
+        unpack_qubits<D>(s, q + (size_t)e * L::NQ);
+        unpack_state<D>(s.v, s.p, st + (size_t)e * L::NQ);
+    }
+}
+template <int D>
+static void t_step(int n, uint8_t* q, const int32_t* act, uint8_t* st, int32_t* ground) {
+    using L = Lat<D>;
+    for (int e = 0; e < n; ++e) {
+        typename L::State s;
+        pack_qubits<D>(q + (size_t)e * L::NQ, s);
+        L::apply(s, act[4 * e], act[4 * e + 1], act[4 * e + 2], act[4 * e + 3]);
+        L::syndrome(s);
+        unpack_qubits<D>(s, q + (size_t)e * L::NQ);
+        unpack_state<D>(s.v, s.p, st + (size_t)e * L::NQ);
+        ground[e] = L::ground_state(s);
+    }
+}
+
+#define DISPATCH(d, CALL)                  \
+    switch (d) {                           \
+        case 3: CALL(3); break;            \
+        case 5: CALL(5); break;            \
+        case 7: CALL(7); break;            \
+        case 9: CALL(9); break;            \
+        case 11: CALL(11); break;          \
+        case 13: CALL(13); break;          \
+        default: return -1;                \
+    }                                      \
+    return 0;
+
+extern "C" {
+int shim_syndrome(int d, int n, const uint8_t* q, uint8_t* st) {
+#define C_(D) t_syndrome<D>(n, q, st)
+    DISPATCH(d, C_)
+#undef C_
+}
+int shim_counts(int d, int n, const uint8_t* st, int32_t* counts, uint8_t* masks) {
+#define C_(D) t_counts<D>(n, st, counts, masks)
+    DISPATCH(d, C_)
+#undef C_
+}
+int shim_lut(int d, int32_t* lut) {
+#define C_(D) t_lut<D>(lut)
+    DISPATCH(d, C_)
+#undef C_
+}
+int shim_perspective(int d, int n, const uint8_t* st, const int32_t* act, uint8_t* out) {
+#define C_(D) t_perspective<D>(n, st, act, out)
+    DISPATCH(d, C_)
+#undef C_
+}
+int shim_reset(int d, int n, uint64_t seed, int64_t first_env, const uint32_t* episodes, const double* p,
+               uint8_t* q, uint8_t* st, int32_t* rounds) {
+#define C_(D) t_reset<D>(n, seed, first_env, episodes, p, q, st, rounds)
+    DISPATCH(d, C_)
+#undef C_
+}
+int shim_step(int d, int n, uint8_t* q, const int32_t* act, uint8_t* st, int32_t* ground) {
+#define C_(D) t_step<D>(n, q, act, st, ground)
+    DISPATCH(d, C_)
+#undef C_
+}
+void shim_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+    U4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+}

@@ -1,0 +1,71 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol that
+include/toricenv.h declares; pure-host entry points behave; nothing here launches a kernel."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import toric_rl_decoder_amd as T
+from toric_rl_decoder_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    T.build()
+    return T.load()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "toricenv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tq_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    declared = header_functions()
+    assert len(declared) >= 25
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert set(declared) == bound
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+
+
+def test_version_and_block_layout(lib):
+    assert lib.tq_version() == 100
+    # d=7: W=1 -> 4*8 + 4 + 4 + 1 bytes per transition, sections 8-byte aligned
+    assert lib.tq_transition_block_bytes(7, 8) == 4 * 8 * 8 + 32 + 32 + 8
+    assert lib.tq_transition_block_bytes(9, 1000) == 4 * 8 * 2 * 1000 + 4000 + 4000 + 1000
+    assert lib.tq_transition_block_bytes(4, 8) == -1
+    assert lib.tq_transition_block_bytes(7, -1) == -1
+
+
+def test_errors_are_codes_not_aborts(lib):
+    h = C.c_void_p(None)
+    rc = lib.tq_create(C.byref(h), 0, 7, 0, 1, 0)
+    assert rc == _lib.TQ_E_INVALID and b"n_envs" in lib.tq_last_error()
+    rc = lib.tq_create(C.byref(h), 8, 6, 0, 1, 0)
+    assert rc == _lib.TQ_E_INVALID and b"unsupported lattice size" in lib.tq_last_error()
+    assert lib.tq_set_params(None, 0.1, 100.0, 75) == _lib.TQ_E_INVALID
+    assert lib.tq_destroy(None) == 0
+    if not torch.cuda.is_available():
+        rc = lib.tq_create(C.byref(h), 8, 7, 0, 1, 0)       # no HIP device: an error code, not a crash
+        assert rc < 0 and lib.tq_last_error()
+
+
+def test_python_surface_fails_loudly_without_gpu():
+    env = T.make("toric-code-v0", {"size": 5, "min_qubit_errors": 0, "p_error": 0.1})
+    assert env.system_size == 5 and int(env.action_space.high[-1]) == 3
+    with pytest.raises(ValueError):
+        T.make("toric-code-v0", {"size": 4})
+    with pytest.raises(ValueError):
+        T.make("cartpole", {})
+    if not torch.cuda.is_available():
+        with pytest.raises(T.ToricEnvError):
+            T.EnvSet(env, 4)
+    dt = T.transition_dtype(7)
+    assert dt.itemsize == 1609                               # reference record at d=7

@@ -1,0 +1,374 @@
+"""Parity of the HIP path (through the C-ABI) with the oracle, bit-exact, on a real MI355X.
+
+Run with ``pytest -m gpu``.  Every comparison is integer/byte exact; the only floats are
+rewards (small integers) and Q-values that are copied, never computed.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import toric_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (3, 5, 7, 9, 11)
+P_OF = {3: 0.1, 5: 0.1, 7: 0.1, 9: 0.15, 11: 0.1}
+
+
+@pytest.fixture(scope="module")
+def T():
+    import toric_rl_decoder_amd as T
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    assert os.path.exists(T.LIB_PATH), "libtoricenv.so must be built (no fallback path exists)"
+    T.load()
+    return T
+
+
+def make_pair(T, d, n, p=None, seed=1234, first=0, numpy_io=True, **kw):
+    p = P_OF[d] if p is None else p
+    env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": 0, "p_error": p})
+    gpu = T.EnvSet(env, n, seed=seed, first_env_id=first, numpy_io=numpy_io, **kw)
+    ora = O.OracleEnvSet(d, n, p, seed=seed, first_env_id=first)
+    return gpu, ora
+
+
+def random_actions_from(pos, off, rng):
+    n = off.shape[0] - 1
+    cnt = off[1:] - off[:-1]
+    pick = off[:-1] + (rng.random(n) * cnt).astype(np.int64)
+    a = np.zeros((n, 4), np.int64)
+    a[:, :3] = pos[pick]
+    a[:, 3] = rng.integers(1, 4, n)
+    return a
+
+
+# ------------------------------------------------------------------ EnvSet surface, every size
+@pytest.mark.parametrize("d", SIZES)
+def test_envset_surface_parity(T, d):
+    n = 500                                     # not a multiple of the 256-thread workgroup
+    gpu, ora = make_pair(T, d, n, first=37)
+    s = gpu.resetAll()
+    os_ = ora.resetAll()
+    assert s.dtype == np.int64 and np.array_equal(s, os_)
+    assert np.array_equal(gpu.getQubits(), ora.qubits)
+    rng = np.random.default_rng(d)
+    for t in range(16):
+        per, pos, cnt = gpu.generatePerspective()
+        bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+        assert per.dtype == np.float32 and np.array_equal(per, bp.astype(np.float32))
+        assert np.array_equal(pos, bpos) and np.array_equal(cnt, bcnt)
+        q = rng.standard_normal((per.shape[0], 3)).astype(np.float32)
+        q[rng.integers(0, q.shape[0], 16)] = q.max()                       # ties -> first maximum
+        eps = rng.random(n)
+        act, qv = gpu.selectAction(q, eps)
+        oact, oqv, _ = O.select_action_batch(q, boff, bpos, eps, ora.seed, ora.env_ids, ora.episodes, ora.steps)
+        assert np.array_equal(act, oact) and np.array_equal(qv, oqv)
+        prev = ora.states.copy()
+        ns, rew, term, info = gpu.step(act)
+        ons, orew, oterm, _ = ora.step(oact)
+        assert np.array_equal(ns, ons) and np.array_equal(rew, orew) and np.array_equal(term, oterm)
+        assert rew.dtype == np.float64 and term.dtype == bool and info == {}
+        tr = gpu.generateTransition(act)
+        tper, tact, tnper = O.generate_transition_batch(oact, prev, ora.states)
+        assert np.array_equal(tr["perspective"], tper) and np.array_equal(tr["next_perspective"], tnper)
+        assert np.array_equal(tr["action"], tact)
+        assert np.array_equal(gpu.evalGroundState(), O.eval_ground_state(ora.qubits))
+        assert np.array_equal(gpu.isTerminal(), oterm)
+        done = term | (ora.steps > 6)
+        idx = np.nonzero(done)[0]
+        if idx.size:
+            p_new = rng.uniform(0.05, 0.2, idx.size)
+            rs = gpu.resetTerminalEnvs(idx, p_new)
+            ors = ora.resetTerminalEnvs(idx, p_new)
+            assert rs.dtype == np.float64 and np.array_equal(rs, ors)
+        ep, st = gpu.getCounters()
+        assert np.array_equal(ep, ora.episodes) and np.array_equal(st, ora.steps)
+    gpu.close()
+
+
+# ------------------------------------------------------------------ BASELINE configs[1]
+def test_config2_4096_envs_d5_bit_exact(T):
+    """4096 envs, d=5, p=0.10, seed 1234: reset + 64 random-action steps; qubits, syndrome, reward,
+    terminal, perspective stack, positions, counts compared every step."""
+    d, n = 5, 4096
+    gpu, ora = make_pair(T, d, n, p=0.10, seed=1234)
+    assert np.array_equal(gpu.resetAll(), ora.resetAll())
+    rng = np.random.default_rng(1234)
+    for t in range(64):
+        per, pos, cnt = gpu.generatePerspective(dtype=torch.uint8)
+        bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+        assert np.array_equal(per, bp) and np.array_equal(pos, bpos) and np.array_equal(cnt, bcnt)
+        act = random_actions_from(bpos, boff, rng)
+        ns, rew, term, _ = gpu.step(act)
+        ons, orew, oterm, _ = ora.step(act)
+        assert np.array_equal(ns, ons) and np.array_equal(rew, orew) and np.array_equal(term, oterm)
+        assert np.array_equal(gpu.getQubits(), ora.qubits)
+        idx = np.nonzero(term | (ora.steps > 75))[0]
+        if idx.size:
+            assert np.array_equal(gpu.resetTerminalEnvs(idx), ora.resetTerminalEnvs(idx))
+    gpu.close()
+
+
+# ------------------------------------------------------------------ reference golden vectors on the GPU
+@pytest.mark.parametrize("d", (3, 5, 7, 9))
+def test_golden_reference_vectors(T, golden_dir, d):
+    g = np.load(os.path.join(golden_dir, f"reference_d{d}.npz"), allow_pickle=False)
+    per, pos, cnt = T.generatePerspectiveBatch(d // 2, d, g["states"], dtype=torch.float32)
+    assert np.array_equal(per.cpu().numpy(), g["perspectives"].astype(np.float32))
+    assert np.array_equal(pos.cpu().numpy(), g["positions"]) and np.array_equal(cnt.cpu().numpy(), g["counts"])
+    # transitions of the fixture through the stateless drop-in (util_actor.py:223-264 signature)
+    act = np.concatenate((g["t_actions"][:, :3], g["t_op"][:, None]), axis=1).astype(np.int64)
+    rec = T.generateTransitionParallel(act, g["t_reward"], g["states"], g["t_next_states"], g["t_terminal"], d // 2)
+    assert np.array_equal(rec["perspective"], g["t_perspective"])
+    assert np.array_equal(rec["next_perspective"], g["t_next_perspective"])
+    assert np.array_equal(rec["action"]["position"], g["t_position"]) and np.array_equal(rec["action"]["op"], g["t_op"])
+    assert np.array_equal(rec["reward"], g["t_reward"]) and np.array_equal(rec["terminal"], g["t_terminal"])
+
+
+@pytest.mark.parametrize("dtype", (torch.float16, torch.bfloat16, torch.uint8))
+def test_output_dtypes(T, dtype):
+    d, n = 7, 300
+    gpu, ora = make_pair(T, d, n, numpy_io=False)
+    gpu.resetAll()
+    ora.resetAll()
+    per, pos, cnt = gpu.generatePerspective(dtype=dtype)
+    bp, bpos, bcnt, _ = O.generate_perspective_batch(ora.states)
+    assert per.dtype == dtype
+    assert np.array_equal(per.float().cpu().numpy(), bp.astype(np.float32))
+    assert np.array_equal(pos.cpu().numpy(), bpos)
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_full_and_single_lattice(T):
+    d = 5
+    env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+    gpu = T.EnvSet(env, 3, seed=1)
+    q = np.zeros((3, 2, d, d), np.uint8)
+    q[1, 0] = 3                      # Z everywhere on layer 0: every vertex touched twice -> empty
+    q[2, 0, 1, 1] = 2                # one Y: 2 vertex + 2 plaquette defects
+    gpu.setQubits(q)
+    s = gpu.getStates()
+    assert np.array_equal(s, O.syndrome(q)) and s[0].sum() == 0 and s[1].sum() == 0 and s[2].sum() == 4
+    per, pos, cnt = gpu.generatePerspective()
+    bp, bpos, bcnt, _ = O.generate_perspective_batch(O.syndrome(q))
+    assert cnt.tolist() == bcnt.tolist() and cnt[0] == 0 and cnt[1] == 0
+    assert np.array_equal(per, bp.astype(np.float32)) and np.array_equal(pos, bpos)
+    act, qv = gpu.selectAction(np.zeros((per.shape[0], 3), np.float32), np.zeros(3))
+    assert act[0].tolist() == [0, 0, 0, 0] and act[1].tolist() == [0, 0, 0, 0]   # empty syndrome: no legal action
+    assert np.array_equal(gpu.isTerminal(), [True, True, False])
+    assert np.array_equal(gpu.evalGroundState(), O.eval_ground_state(q))
+    gpu.close()
+    one = T.EnvSet(env, 1, seed=9)
+    o1 = O.OracleEnvSet(d, 1, 0.1, seed=9)
+    assert np.array_equal(one.resetAll(), o1.resetAll())
+    per, pos, cnt = one.generatePerspective()
+    bp, bpos, _, _ = O.generate_perspective_batch(o1.states)
+    assert np.array_equal(per, bp.astype(np.float32)) and np.array_equal(pos, bpos)
+    one.close()
+
+
+def test_dense_syndrome_maximum_size(T):
+    """Every qubit a hit: the maximum stack (2*d*d perspectives per lattice)."""
+    d, n = 7, 64
+    rng = np.random.default_rng(3)
+    st = (rng.random((n, 2, d, d)) < 0.6).astype(np.uint8)
+    st[0] = 1
+    per, pos, cnt = T.generatePerspectiveBatch(d // 2, d, st, dtype=torch.uint8)
+    bp, bpos, bcnt, _ = O.generate_perspective_batch(st)
+    assert int(cnt[0]) == 2 * d * d
+    assert np.array_equal(per.cpu().numpy(), bp) and np.array_equal(pos.cpu().numpy(), bpos)
+    assert np.array_equal(cnt.cpu().numpy(), bcnt)
+
+
+def test_bad_actions_and_capacity_are_reported(T):
+    d, n = 5, 100
+    gpu, ora = make_pair(T, d, n)
+    gpu.resetAll()
+    bad = np.zeros((n, 4), np.int64)
+    bad[:, 3] = 1
+    bad[7] = (0, d, 0, 1)                                  # row out of range
+    with pytest.raises(ValueError):
+        gpu.step(bad)
+    bad[7] = (0, 0, 0, 4)                                  # op outside 1..3
+    with pytest.raises(ValueError):
+        gpu.step(bad)
+    with pytest.raises(ValueError):
+        gpu.step(np.zeros((n - 1, 4), np.int64))
+    with pytest.raises(ValueError):
+        gpu.resetTerminalEnvs([0, 0])
+    with pytest.raises(ValueError):
+        gpu.resetTerminalEnvs([n])
+    cnt, off = gpu.perspectiveCounts()
+    P = int(off[-1].item())
+    small = torch.zeros((P - 1, 2, d, d), dtype=torch.float32, device=gpu.device)
+    gpu.writePerspectives(small)
+    with pytest.raises(T.ToricEnvError):
+        gpu.check()
+    gpu.check()                                            # latch is cleared by the read
+    gpu.close()
+
+
+# ------------------------------------------------------------------ fused actor step
+@pytest.mark.parametrize("d,strategy", [(3, "random"), (5, "linear"), (7, "fixed"), (9, "random")])
+def test_fused_actor_step_matches_oracle_loop(T, d, strategy):
+    """tq_actor_step (step -> transition -> scheduled auto-reset -> counts) against the same loop
+    spelled out with oracle calls in the order of Actor_mp.py:104-185."""
+    n, T_steps, max_steps = 700, 40, 9
+    p0 = P_OF[d]
+    gpu, ora = make_pair(T, d, n, p=p0, seed=77, first=1000, numpy_io=False, max_steps_per_episode=max_steps)
+    p_start, p_final, p_delta = 0.05, 0.2, 0.03
+    gpu.set_perror_schedule(strategy, p_start, p_final, p_delta)
+    roof = np.full(n, p_start)
+    gpu.resetAll()
+    ora.resetAll()
+    blk = gpu.newTransitionBlock(steps=T_steps)
+    log = []
+    for t in range(T_steps):
+        cnt, off = gpu.perspectiveCounts()
+        bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+        assert np.array_equal(cnt.cpu().numpy(), bcnt) and np.array_equal(off.cpu().numpy(), boff)
+        oact, _, _ = O.select_action_batch(np.zeros((bp.shape[0], 3), np.float32), boff, bpos, 1.0, ora.seed,
+                                           ora.env_ids, ora.episodes, ora.steps)
+        act, rew, term = gpu.actorStep(None, block=blk, slot=t)
+        prev = ora.states.copy()
+        ons, orew, oterm, _ = ora.step(oact)
+        assert np.array_equal(act.cpu().numpy(), oact)
+        assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32))
+        assert np.array_equal(term.cpu().numpy().astype(bool), oterm)
+        tper, tact, tnper = O.generate_transition_batch(oact, prev, ora.states)
+        log.append((tper, tact, tnper, orew.astype(np.float32), oterm))
+        idx = np.nonzero(oterm | (ora.steps > max_steps))[0]
+        if idx.size:
+            if strategy == "fixed":
+                p_new = np.full(idx.size, p0)
+            else:
+                roof[idx] = np.minimum(p_final, roof[idx] + p_delta)
+                p_new = O.perror_schedule(ora.seed, ora.env_ids[idx], ora.episodes[idx], p_start, roof[idx], strategy)
+            ora.resetTerminalEnvs(idx, p_new)
+        assert np.array_equal(gpu.getStates().cpu().numpy(), ora.states)
+        assert np.array_equal(gpu.getQubits().cpu().numpy(), ora.qubits)
+    ep, st = gpu.getCounters()
+    assert np.array_equal(ep.cpu().numpy(), ora.episodes) and np.array_equal(st.cpu().numpy(), ora.steps)
+    assert ora.episodes.max() >= 3
+    for t in (0, T_steps // 2, T_steps - 1):
+        u = blk.unpack(first=t * n, count=n)
+        tper, tact, tnper, orew, oterm = log[t]
+        assert np.array_equal(u["perspective"].cpu().numpy(), tper)
+        assert np.array_equal(u["next_perspective"].cpu().numpy(), tnper)
+        assert np.array_equal(u["action"].cpu().numpy(), tact)
+        assert np.array_equal(u["reward"].cpu().numpy(), orew)
+        assert np.array_equal(u["terminal"].cpu().numpy().astype(bool), oterm)
+    rec = T.to_structured(blk.unpack(first=0, count=n), d)
+    assert rec.dtype == T.transition_dtype(d) and np.array_equal(rec["reward"], log[0][3].astype(np.float64))
+    gpu.close()
+
+
+def test_fused_step_with_given_actions_equals_unfused(T):
+    d, n = 7, 1000
+    a, _ = make_pair(T, d, n, seed=5, numpy_io=False, max_steps_per_episode=1000)
+    b, _ = make_pair(T, d, n, seed=5, numpy_io=False, max_steps_per_episode=1000)
+    a.resetAll()
+    b.resetAll()
+    for t in range(5):
+        per, pos, cnt = a.generatePerspective(dtype=torch.uint8)
+        b.perspectiveCounts()
+        act, _ = a.selectAction(None, 1.0)
+        act = act.clone()
+        s1, r1, t1, _ = a.step(act)
+        r1, t1 = r1.clone(), t1.clone()
+        _, r2, t2 = b.actorStep(act)
+        assert torch.equal(r1, r2) and torch.equal(t1, t2)
+        live = ~t1.bool()
+        assert torch.equal(a.getStates()[live], b.getStates()[live])
+        idx = torch.nonzero(t1).flatten().int()
+        if idx.numel():
+            a.resetTerminalEnvs(idx)
+        assert torch.equal(a.getStates(), b.getStates()) and torch.equal(a.getQubits(), b.getQubits())
+    a.close()
+    b.close()
+
+
+def test_sharding_is_partition_invariant(T):
+    """Global env ids key the RNG: two shards of 128 lattices == one handle of 256."""
+    d = 7
+    whole, _ = make_pair(T, d, 256, seed=99, first=0, numpy_io=False)
+    lo, _ = make_pair(T, d, 128, seed=99, first=0, numpy_io=False)
+    hi, _ = make_pair(T, d, 128, seed=99, first=128, numpy_io=False)
+    for e in (whole, lo, hi):
+        e.resetAll()
+    for t in range(12):
+        aw, rw, tw = (x.clone() for x in whole.actorStep(None))
+        al, rl, tl = (x.clone() for x in lo.actorStep(None))
+        ah, rh, th = (x.clone() for x in hi.actorStep(None))
+        assert torch.equal(aw, torch.cat((al, ah))) and torch.equal(rw, torch.cat((rl, rh)))
+        assert torch.equal(whole.getStates(), torch.cat((lo.getStates().clone(), hi.getStates().clone())))
+    for e in (whole, lo, hi):
+        e.close()
+
+
+# ------------------------------------------------------------------ single-env facade
+def test_toric_env_facade(T):
+    d = 5
+    env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": 0, "p_error": 0.1}, seed=3)
+    ora = O.OracleEnvSet(d, 1, 0.1, seed=3)
+    s = env.reset()
+    assert np.array_equal(s, ora.resetAll()[0]) and not env.isTerminalState(s)
+    assert np.array_equal(env.qubit_matrix, ora.qubits[0]) and np.array_equal(env.state, s)
+    per, pos, _, _ = O.generate_perspective_batch(ora.states)
+    a = [int(pos[0][0]), int(pos[0][1]), int(pos[0][2]), 2]
+    ns, r, t, _ = env.step(a)
+    ons, orew, oterm, _ = ora.step(np.array([a]))
+    assert np.array_equal(ns, ons[0]) and r == orew[0] and t == bool(oterm[0])
+    s2 = env.reset(p_error=0.2)
+    assert np.array_equal(s2, ora.resetTerminalEnvs([0], [0.2])[0])
+    qm = np.zeros((2, d, d), np.int64)
+    qm[0, 2, :] = 1
+    assert np.array_equal(env.createSyndromOpt(qm), O.syndrome(qm)) and env.isTerminalState(env.createSyndromOpt(qm))
+    env.qubit_matrix = qm                                   # small_p_error_test.py:119-120 pattern
+    assert env.isTerminalState(env.state) and env.evalGroundState() is False
+    env.qubit_matrix = np.zeros((2, d, d), np.int64)
+    assert env.evalGroundState() is True
+
+
+# ------------------------------------------------------------------ BASELINE full sizes
+@pytest.mark.parametrize("d,p,n", [(7, 0.10, 65536), (9, 0.15, 65536)])
+def test_full_size_configs(T, d, p, n):
+    """configs[2] / configs[3]: exact counts/offsets against the oracle for all 65 536 lattices,
+    exact stack compare on a strided subset, and size-independent properties on the whole stack:
+    every perspective is a permutation of its lattice's syndrome (equal defect count) and has a
+    defect on one of the four centre checks (centred-frame property)."""
+    gpu, _ = make_pair(T, d, n, p=p, seed=2020, numpy_io=False)
+    gpu.resetAll()
+    for _ in range(3):
+        gpu.actorStep(None)
+    states = gpu.getStates().clone()
+    st_np = states.cpu().numpy()
+    assert np.array_equal(O.syndrome(gpu.getQubits().cpu().numpy()), st_np)
+    per, pos, cnt = gpu.generatePerspective(dtype=torch.float32)
+    hm = O.hit_masks(st_np).reshape(n, -1)
+    ocnt = hm.sum(1).astype(np.int32)
+    assert np.array_equal(cnt.cpu().numpy(), ocnt)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(ocnt, out=off[1:])
+    assert per.shape[0] == off[-1]
+    # positions: exact for all lattices
+    env_idx, hit = np.nonzero(hm)
+    layer, rem = np.divmod(hit, d * d)
+    assert np.array_equal(pos.cpu().numpy(), np.stack((layer, rem // d, rem % d), 1))
+    # properties over the full stack (on the device)
+    defects = states.reshape(n, -1).sum(1).to(torch.float32)
+    owner = torch.repeat_interleave(torch.arange(n, device=per.device), cnt.long())
+    assert torch.equal(per.reshape(per.shape[0], -1).sum(1), defects[owner])
+    gs = d // 2
+    centre = per[:, 0, gs, gs] + per[:, 0, gs + 1, gs] + per[:, 1, gs, gs] + per[:, 1, gs, gs - 1]
+    assert bool((centre > 0).all())
+    assert bool(((per == 0) | (per == 1)).all())
+    # exact compare on a strided subset of lattices (first, last, every 97th)
+    sel = np.unique(np.concatenate((np.arange(0, n, 97), [n - 1])))
+    bp, _, _, _ = O.generate_perspective_batch(st_np[sel])
+    rows = np.concatenate([np.arange(off[e], off[e + 1]) for e in sel])
+    got = per[torch.as_tensor(rows, device=per.device)].cpu().numpy()
+    assert np.array_equal(got, bp.astype(np.float32))
+    gpu.close()

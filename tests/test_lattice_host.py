@@ -1,0 +1,84 @@
+"""Unit test of the product's bit-plane header (toric-rl-decoder_amd/csrc/lattice.hpp) on the CPU:
+tests/host_lattice_shim.cpp instantiates the same templates the HIP kernels use, g++ builds it
+into a temp dir, and every operation is compared with the oracle.  Test-only build: the product
+itself has no CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import toric_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZES = (3, 5, 7, 9, 11, 13)
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    out = tmp_path_factory.mktemp("shim") / "libshim.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                           "-I", os.path.join(ROOT, "toric-rl-decoder_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_lattice_shim.cpp"), "-o", str(out)])
+    return C.CDLL(str(out))
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("d", SIZES)
+def test_bitplane_algebra(shim, d):
+    rng = np.random.default_rng(d)
+    n, nq = 300, 2 * d * d
+    q = rng.integers(0, 4, (n, 2, d, d)).astype(np.uint8)
+    q[rng.random(q.shape) < 0.7] = 0
+    st = np.zeros_like(q)
+    assert shim.shim_syndrome(d, n, P(q), P(st)) == 0
+    assert np.array_equal(st, O.syndrome(q))
+
+    cnt = np.zeros(n, np.int32)
+    masks = np.zeros_like(q)
+    shim.shim_counts(d, n, P(st), P(cnt), P(masks))
+    hm = O.hit_masks(st)
+    assert np.array_equal(masks.astype(bool), hm) and np.array_equal(cnt, hm.reshape(n, -1).sum(1))
+
+    lut = np.zeros((nq, nq), np.int32)
+    shim.shim_lut(d, P(lut))
+    assert np.array_equal(lut, O.perspective_source_index(d).reshape(nq, nq))
+
+    act = np.stack((rng.integers(0, 2, n), rng.integers(0, d, n), rng.integers(0, d, n), rng.integers(1, 4, n)),
+                   1).astype(np.int32)
+    dense = (rng.random((n, 2, d, d)) < 0.5).astype(np.uint8)
+    out = np.zeros_like(dense)
+    shim.shim_perspective(d, n, P(dense), P(act), P(out))
+    per, _, _ = O.generate_transition_batch(act, dense, dense)
+    assert np.array_equal(out, per)
+
+    qq, st3, g = q.copy(), np.zeros_like(q), np.zeros(n, np.int32)
+    shim.shim_step(d, n, P(qq), P(act), P(st3), P(g))
+    oq, ns, _, _ = O.step_lattices(q, st, act)
+    assert np.array_equal(qq, oq) and np.array_equal(st3, ns)
+    assert np.array_equal(g.astype(bool), O.eval_ground_state(oq))
+
+
+@pytest.mark.parametrize("d", SIZES)
+def test_reset_matches_oracle(shim, d):
+    rng = np.random.default_rng(100 + d)
+    n = 300
+    ep = rng.integers(0, 5, n).astype(np.uint32)
+    p = np.full(n, 0.1)
+    p[:60] = 0.02
+    q, st, rounds = np.zeros((n, 2, d, d), np.uint8), np.zeros((n, 2, d, d), np.uint8), np.zeros(n, np.int32)
+    shim.shim_reset(d, n, C.c_uint64(99), C.c_int64(5), P(ep), P(p), P(q), P(st), P(rounds))
+    oq, os_ = O.reset_lattices(99, np.arange(5, 5 + n), ep, p, d)
+    assert np.array_equal(q, oq) and np.array_equal(st, os_)
+    assert rounds.min() >= 1 and (d > 3 or rounds.max() > 1)
+
+
+def test_philox_header(shim):
+    out = np.zeros(4, np.uint32)
+    shim.shim_philox(P(np.array([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], np.uint32)),
+                     P(np.array([0xa4093822, 0x299f31d0], np.uint32)), P(out))
+    assert [int(x) for x in out] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]

@@ -1,0 +1,13 @@
+"""toric-rl-decoder_amd: MI355X-native batched toric-code RL environment.
+
+The env hot path of Lindeby/toric-RL-decoder (EnvSet / gym_ToricCode step loop,
+generatePerspective, transitions, epsilon-greedy selection) as hand-written HIP kernels
+for gfx950 behind a C-ABI (include/toricenv.h), with the reference's Python surface on top.
+Import it as ``toric_rl_decoder_amd`` (the directory name has a hyphen).
+"""
+from ._lib import ToricEnvError, build, load, LIB_PATH  # noqa: F401
+from .envset import (EnvSet, ToricEnv, TransitionBlock, generatePerspectiveBatch,  # noqa: F401
+                     generateTransitionParallel, make, to_structured, transition_dtype, SUPPORTED_SIZES)
+
+__all__ = ["EnvSet", "ToricEnv", "TransitionBlock", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
+           "transition_dtype", "ToricEnvError", "build", "load", "LIB_PATH", "SUPPORTED_SIZES"]

@@ -1,0 +1,615 @@
+// HIP kernels of the batched toric-code environment (gfx950 / CDNA4).
+//
+// Data layout in HBM (per handle, N lattices, W = ceil(d*d/64)):
+//   planes  u64[6][W][N]   bit-planes X0 X1 Z0 Z1 V P, structure-of-arrays over lattices, so the
+//                          thread-per-lattice kernels load/store 8 B per lane fully coalesced
+//   prev    u64[2][W][N]   V,P before the last tq_step (for tq_transition_write)
+//   counts  i32[N], offsets i64[N+1], episodes/steps u32[N], p_roof f64[N]
+//
+// Two kernel shapes:
+//   * env dynamics (reset / step / transition / fused actor step): ONE THREAD PER LATTICE.
+//     In bit-plane form a whole-lattice syndrome is ~20 shifts/xors, so there is nothing to
+//     share between lanes; 65 536 lattices = 1 024 wavefronts.
+//   * perspective stack write (the HBM-bound kernel): ONE WAVEFRONT PER LATTICE.  The hit list,
+//     the syndrome cells and the (hit, cell) -> source-cell table sit in LDS; periodic shifts and
+//     the layer-1 rotation are LDS index lookups; every lane stores 16 B, so one wave
+//     instruction writes 1 KiB of the contiguous (n_hits, 2, d, d) segment of its lattice.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "lattice.hpp"
+
+namespace tq {
+
+enum { PL_X0 = 0, PL_X1 = 1, PL_Z0 = 2, PL_Z1 = 3, PL_V = 4, PL_P = 5 };
+enum { ERR_ACTION = 1, ERR_CAPACITY = 2 };
+
+template <int W>
+__device__ __forceinline__ Bits<W> load_plane(const uint64_t* __restrict__ planes, int plane, int64_t N, int64_t e) {
+    Bits<W> b;
+#pragma unroll
+    for (int k = 0; k < W; ++k) b.w[k] = planes[((int64_t)plane * W + k) * N + e];
+    return b;
+}
+template <int W>
+__device__ __forceinline__ void store_plane(uint64_t* __restrict__ planes, int plane, int64_t N, int64_t e, const Bits<W>& b) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) planes[((int64_t)plane * W + k) * N + e] = b.w[k];
+}
+template <int D>
+__device__ __forceinline__ typename Lat<D>::State load_state(const uint64_t* __restrict__ planes, int64_t N, int64_t e) {
+    constexpr int W = Lat<D>::W;
+    typename Lat<D>::State s;
+    s.x[0] = load_plane<W>(planes, PL_X0, N, e);
+    s.x[1] = load_plane<W>(planes, PL_X1, N, e);
+    s.z[0] = load_plane<W>(planes, PL_Z0, N, e);
+    s.z[1] = load_plane<W>(planes, PL_Z1, N, e);
+    s.v = load_plane<W>(planes, PL_V, N, e);
+    s.p = load_plane<W>(planes, PL_P, N, e);
+    return s;
+}
+template <int D>
+__device__ __forceinline__ void store_state(uint64_t* __restrict__ planes, int64_t N, int64_t e, const typename Lat<D>::State& s) {
+    constexpr int W = Lat<D>::W;
+    store_plane<W>(planes, PL_X0, N, e, s.x[0]);
+    store_plane<W>(planes, PL_X1, N, e, s.x[1]);
+    store_plane<W>(planes, PL_Z0, N, e, s.z[0]);
+    store_plane<W>(planes, PL_Z1, N, e, s.z[1]);
+    store_plane<W>(planes, PL_V, N, e, s.v);
+    store_plane<W>(planes, PL_P, N, e, s.p);
+}
+
+// Position of the k-th set bit (k < popc) of the concatenated hit mask [E0 | E1] as a flat
+// qubit index layer*DD + row*D + col -- the k-th entry of the reference's positions list.
+template <int D>
+__device__ __forceinline__ int kth_hit(const typename Lat<D>::B& e0, const typename Lat<D>::B& e1, int k) {
+    constexpr int W = Lat<D>::W;
+    constexpr int DD = Lat<D>::DD;
+    int base = 0;
+    uint64_t word = 0;
+    bool found = false;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const uint64_t wv = l ? e1.w[j] : e0.w[j];
+            const int c = popc64(wv);
+            const bool here = !found && k < c;
+            word = here ? wv : word;
+            base = here ? l * DD + 64 * j : base;
+            k = (found || here) ? k : k - c;
+            found = found || here;
+        }
+    }
+    for (int t = 0; t < k; ++t) word &= word - 1;      // drop the k lowest set bits
+    return base + (int)__ffsll((long long)word) - 1;
+}
+
+struct PerrSchedule {
+    int strategy;          // TQ_PERR_*
+    double p_default, p_start, p_final, p_delta;
+};
+
+// ------------------------------------------------------------------ reset
+// env.reset(p_error) per lattice (EnvSet.py:19-36).  idx == nullptr: all lattices.
+template <int D>
+__global__ __launch_bounds__(256) void k_reset(uint64_t* __restrict__ planes, uint32_t* __restrict__ episodes,
+                                               uint32_t* __restrict__ steps, int32_t* __restrict__ counts,
+                                               const int32_t* __restrict__ idx, int n_idx,
+                                               const double* __restrict__ p_err, double p_default,
+                                               uint64_t seed, int64_t first_env, int64_t N) {
+    using L = Lat<D>;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t m = idx ? n_idx : N;
+    if (t >= m) return;
+    const int64_t e = idx ? idx[t] : t;
+    if (e < 0 || e >= N) return;
+    typename L::State s;
+    const uint32_t ep = episodes[e];
+    reset_lattice<D>(s, seed, (uint32_t)(first_env + e), ep, p_err ? p_err[t] : p_default);
+    store_state<D>(planes, N, e, s);
+    episodes[e] = ep + 1;
+    steps[e] = 0;
+    counts[e] = L::persp_count(s.v, s.p);
+}
+
+// validated decode of action = [layer,row,col,op]
+template <int D>
+__device__ __forceinline__ bool action_ok(int layer, int row, int col, int op) {
+    return ((unsigned)layer < 2u) & ((unsigned)row < (unsigned)D) & ((unsigned)col < (unsigned)D) &
+           ((unsigned)(op - 1) < 3u);
+}
+
+// ------------------------------------------------------------------ step (EnvSet.step)
+template <int D>
+__global__ __launch_bounds__(256) void k_step(uint64_t* __restrict__ planes, uint64_t* __restrict__ prev,
+                                              const int32_t* __restrict__ actions, float* __restrict__ rewards,
+                                              uint8_t* __restrict__ terminals, uint32_t* __restrict__ steps,
+                                              int32_t* __restrict__ counts, float terminal_reward, int64_t N,
+                                              int* __restrict__ err) {
+    using L = Lat<D>;
+    constexpr int W = L::W;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    typename L::State s = load_state<D>(planes, N, e);
+    const int4 a = reinterpret_cast<const int4*>(actions)[e];
+    store_plane<W>(prev, 0, N, e, s.v);
+    store_plane<W>(prev, 1, N, e, s.p);
+    const int before = s.v.popc() + s.p.popc();
+    if (action_ok<D>(a.x, a.y, a.z, a.w)) L::apply(s, a.x, a.y, a.z, a.w);
+    else atomicOr(err, ERR_ACTION);
+    L::syndrome(s);
+    const int after = s.v.popc() + s.p.popc();
+    store_state<D>(planes, N, e, s);
+    if (rewards) rewards[e] = after == 0 ? terminal_reward : (float)(before - after);
+    if (terminals) terminals[e] = after == 0;
+    steps[e] += 1;
+    counts[e] = L::persp_count(s.v, s.p);
+}
+
+// ------------------------------------------------------------------ packed transition block
+struct BlockView {     // SoA sections of a packed transition block (see include/toricenv.h)
+    uint64_t* pv; uint64_t* pp; uint64_t* nv; uint64_t* np;
+    uint32_t* action; float* reward; uint8_t* terminal;
+    int64_t cap;
+};
+__host__ __device__ inline int64_t align8(int64_t x) { return (x + 7) & ~(int64_t)7; }
+__host__ __device__ inline BlockView block_view(void* base, int W, int64_t cap) {
+    BlockView b;
+    char* p = (char*)base;
+    b.cap = cap;
+    b.pv = (uint64_t*)p; p += 8 * (int64_t)W * cap;
+    b.pp = (uint64_t*)p; p += 8 * (int64_t)W * cap;
+    b.nv = (uint64_t*)p; p += 8 * (int64_t)W * cap;
+    b.np = (uint64_t*)p; p += 8 * (int64_t)W * cap;
+    b.action = (uint32_t*)p; p += align8(4 * cap);
+    b.reward = (float*)p; p += align8(4 * cap);
+    b.terminal = (uint8_t*)p;
+    return b;
+}
+__host__ __device__ inline int64_t block_bytes(int W, int64_t cap) {
+    return 4 * 8 * (int64_t)W * cap + 2 * align8(4 * cap) + align8(cap);
+}
+
+template <int D>
+__device__ __forceinline__ void write_transition(const BlockView& b, int64_t slot, const typename Lat<D>::B& v0,
+                                                 const typename Lat<D>::B& p0, const typename Lat<D>::B& v1,
+                                                 const typename Lat<D>::B& p1, int layer, int row, int col, int op,
+                                                 float reward, int terminal) {
+    using L = Lat<D>;
+    constexpr int W = L::W;
+    typename L::B a, c;
+    L::perspective(v0, p0, layer, row, col, a, c);
+#pragma unroll
+    for (int k = 0; k < W; ++k) { b.pv[(int64_t)k * b.cap + slot] = a.w[k]; b.pp[(int64_t)k * b.cap + slot] = c.w[k]; }
+    L::perspective(v1, p1, layer, row, col, a, c);
+#pragma unroll
+    for (int k = 0; k < W; ++k) { b.nv[(int64_t)k * b.cap + slot] = a.w[k]; b.np[(int64_t)k * b.cap + slot] = c.w[k]; }
+    // action rewritten to the centred frame (util_actor.py:256,261)
+    b.action[slot] = (uint32_t)layer | ((uint32_t)L::GS << 8) | ((uint32_t)L::GS << 16) | ((uint32_t)op << 24);
+    b.reward[slot] = reward;
+    b.terminal[slot] = (uint8_t)terminal;
+}
+
+// generateTransitionParallel for the last tq_step, into a packed block
+template <int D>
+__global__ __launch_bounds__(256) void k_transition(const uint64_t* __restrict__ planes, const uint64_t* __restrict__ prev,
+                                                    const int32_t* __restrict__ actions, BlockView b, int64_t slot_base,
+                                                    int64_t N, int* __restrict__ err) {
+    using L = Lat<D>;
+    constexpr int W = L::W;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int4 a = reinterpret_cast<const int4*>(actions)[e];
+    if (!action_ok<D>(a.x, a.y, a.z, a.w)) { atomicOr(err, ERR_ACTION); return; }
+    const auto v0 = load_plane<W>(prev, 0, N, e), p0 = load_plane<W>(prev, 1, N, e);
+    const auto v1 = load_plane<W>(planes, PL_V, N, e), p1 = load_plane<W>(planes, PL_P, N, e);
+    write_transition<D>(b, slot_base + e, v0, p0, v1, p1, a.x, a.y, a.z, a.w, 0.f, 0);
+}
+
+// ------------------------------------------------------------------ fused actor step
+// Actor_mp.py:116-183 after the policy: step -> transition -> reset(terminal | too many steps)
+// -> perspective counts.  actions == nullptr: pure exploration (eps = 1) drawn in-kernel.
+template <int D>
+__global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ planes, uint32_t* __restrict__ episodes,
+                                                    uint32_t* __restrict__ steps, int32_t* __restrict__ counts,
+                                                    double* __restrict__ p_roof, const int32_t* __restrict__ actions,
+                                                    int32_t* __restrict__ actions_out, float* __restrict__ rewards,
+                                                    uint8_t* __restrict__ terminals, BlockView blk, int has_block,
+                                                    int64_t slot_base, PerrSchedule sched, float terminal_reward,
+                                                    int max_steps, uint64_t seed, int64_t first_env, int64_t N,
+                                                    int* __restrict__ err) {
+    using L = Lat<D>;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    typename L::State s = load_state<D>(planes, N, e);
+    uint32_t ep = episodes[e], st = steps[e];
+    const uint32_t env = (uint32_t)(first_env + e);
+    int layer, row, col, op;
+    bool ok;
+    if (actions) {
+        const int4 a = reinterpret_cast<const int4*>(actions)[e];
+        layer = a.x; row = a.y; col = a.z; op = a.w;
+        ok = action_ok<D>(layer, row, col, op);
+        if (!ok) atomicOr(err, ERR_ACTION);
+    } else {
+        // non-greedy branch of _selectActionBatch_prime (numba/util_actor.py:97-98)
+        typename L::B e0, e1;
+        L::hit_masks(s.v, s.p, e0, e1);
+        const int n = e0.popc() + e1.popc();
+        ok = n > 0;
+        layer = row = col = op = 0;
+        if (ok) {
+            const U4 w = draw(seed, env, ep, st, DOMAIN_SEL, 0);
+            const int h = kth_hit<D>(e0, e1, (int)mulhi32(w.y, (uint32_t)n));
+            layer = h >= L::DD;
+            const int rem = h - layer * L::DD;
+            row = rem / D; col = rem - row * D;
+            op = 1 + (int)mulhi32(w.z, 3);
+        }
+    }
+    if (actions_out) reinterpret_cast<int4*>(actions_out)[e] = make_int4(layer, row, col, op);
+    const typename L::B v0 = s.v, p0 = s.p;
+    const int before = v0.popc() + p0.popc();
+    if (ok) L::apply(s, layer, row, col, op);
+    L::syndrome(s);
+    const int after = s.v.popc() + s.p.popc();
+    const int terminal = after == 0;
+    const float reward = terminal ? terminal_reward : (float)(before - after);
+    st += 1;
+    if (rewards) rewards[e] = reward;
+    if (terminals) terminals[e] = (uint8_t)terminal;
+    if (has_block && ok)
+        write_transition<D>(blk, slot_base + e, v0, p0, s.v, s.p, layer, row, col, op, reward, terminal);
+    // reset policy of the caller (Actor_mp.py:171-183)
+    if (terminal || st > (uint32_t)max_steps) {
+        double p = sched.p_default;
+        if (sched.strategy != 0) {
+            double roof = p_roof[e] + sched.p_delta;
+            roof = roof < sched.p_final ? roof : sched.p_final;
+            p_roof[e] = roof;
+            p = roof;
+            if (sched.strategy == 2) {
+                const U4 w = draw(seed, env, ep, 0, DOMAIN_PERR, 0);
+                const double span = roof - sched.p_start;
+                const double t = span * u01(w.x);
+                p = sched.p_start + t;
+            }
+        }
+        reset_lattice<D>(s, seed, env, ep, p);
+        ep += 1;
+        st = 0;
+    }
+    store_state<D>(planes, N, e, s);
+    episodes[e] = ep;
+    steps[e] = st;
+    counts[e] = L::persp_count(s.v, s.p);
+}
+
+// ------------------------------------------------------------------ u8 views
+// syndrome planes -> u8[n,2,d,d]; one thread per output byte, coalesced byte stores.
+// idx == nullptr: rows 0..n-1 of the handle, else rows idx[0..n).
+template <int D>
+__global__ __launch_bounds__(256) void k_get_state(const uint64_t* __restrict__ planes, int64_t N,
+                                                   const int32_t* __restrict__ idx, int64_t n,
+                                                   uint8_t* __restrict__ out) {
+    using L = Lat<D>;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * L::NQ) return;
+    const int64_t row = t / L::NQ;
+    const int c = (int)(t - row * L::NQ);
+    const int64_t e = idx ? idx[row] : row;
+    if (e < 0 || e >= N) { out[t] = 0; return; }
+    const int plane = c < L::DD ? PL_V : PL_P;
+    const int bit = c < L::DD ? c : c - L::DD;
+    out[t] = (uint8_t)((planes[((int64_t)plane * L::W + (bit >> 6)) * N + e] >> (bit & 63)) & 1);
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_get_qubits(const uint64_t* __restrict__ planes, int64_t N,
+                                                    uint8_t* __restrict__ out) {
+    using L = Lat<D>;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * L::NQ) return;
+    const int64_t e = t / L::NQ;
+    const int c = (int)(t - e * L::NQ);
+    const int layer = c >= L::DD;
+    const int bit = c - layer * L::DD;
+    const int x = (int)((planes[((int64_t)(PL_X0 + layer) * L::W + (bit >> 6)) * N + e] >> (bit & 63)) & 1);
+    const int z = (int)((planes[((int64_t)(PL_Z0 + layer) * L::W + (bit >> 6)) * N + e] >> (bit & 63)) & 1);
+    out[t] = (uint8_t)(z ? (x ? 2 : 3) : x);
+}
+// u8 Pauli codes -> planes (+ syndrome, counts); thread per lattice.
+template <int D>
+__global__ __launch_bounds__(256) void k_set_qubits(uint64_t* __restrict__ planes, int32_t* __restrict__ counts,
+                                                    const uint8_t* __restrict__ q, int64_t N) {
+    using L = Lat<D>;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    typename L::State s;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int k = 0; k < L::W; ++k) {
+            uint64_t ax = 0, az = 0;
+            const int nb = (L::DD - 64 * k) < 64 ? (L::DD - 64 * k) : 64;
+            for (int bit = 0; bit < nb; ++bit) {
+                const int code = q[e * L::NQ + l * L::DD + 64 * k + bit];
+                ax |= (uint64_t)((code == 1) | (code == 2)) << bit;
+                az |= (uint64_t)((code >> 1) & 1) << bit;
+            }
+            s.x[l].w[k] = ax; s.z[l].w[k] = az;
+        }
+    }
+    L::syndrome(s);
+    store_state<D>(planes, N, e, s);
+    counts[e] = L::persp_count(s.v, s.p);
+}
+// u8[n,2,d,d] syndromes -> V/P planes u64[2][W][n] (+ counts); for states outside a handle.
+template <int D>
+__global__ __launch_bounds__(256) void k_pack_states(const uint8_t* __restrict__ st, uint64_t* __restrict__ vp,
+                                                     int32_t* __restrict__ counts, int64_t n) {
+    using L = Lat<D>;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    typename L::B b[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int k = 0; k < L::W; ++k) {
+            uint64_t a = 0;
+            const int nb = (L::DD - 64 * k) < 64 ? (L::DD - 64 * k) : 64;
+            for (int bit = 0; bit < nb; ++bit) a |= (uint64_t)(st[e * L::NQ + l * L::DD + 64 * k + bit] != 0) << bit;
+            b[l].w[k] = a;
+            vp[((int64_t)l * L::W + k) * n + e] = a;
+        }
+    }
+    if (counts) counts[e] = L::persp_count(b[0], b[1]);
+}
+template <int D>
+__global__ __launch_bounds__(256) void k_flags(const uint64_t* __restrict__ planes, int64_t N,
+                                               uint8_t* __restrict__ ground, uint8_t* __restrict__ terminal) {
+    using L = Lat<D>;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const typename L::State s = load_state<D>(planes, N, e);
+    if (ground) ground[e] = (uint8_t)L::ground_state(s);
+    if (terminal) terminal[e] = (uint8_t)!(s.v.any() || s.p.any());
+}
+
+// packed block slots -> u8 grids etc.; thread per output byte of one grid pair
+template <int D>
+__global__ __launch_bounds__(256) void k_block_unpack(BlockView b, int64_t first, int64_t count,
+                                                      uint8_t* __restrict__ persp, uint8_t* __restrict__ next_persp,
+                                                      int32_t* __restrict__ actions, float* __restrict__ rewards,
+                                                      uint8_t* __restrict__ terminals) {
+    using L = Lat<D>;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * L::NQ) return;
+    const int64_t r = t / L::NQ;
+    const int c = (int)(t - r * L::NQ);
+    const int64_t slot = first + r;
+    const int bit = c < L::DD ? c : c - L::DD;
+    const int64_t wi = (int64_t)(bit >> 6) * b.cap + slot;
+    if (persp) persp[t] = (uint8_t)(((c < L::DD ? b.pv : b.pp)[wi] >> (bit & 63)) & 1);
+    if (next_persp) next_persp[t] = (uint8_t)(((c < L::DD ? b.nv : b.np)[wi] >> (bit & 63)) & 1);
+    if (c == 0) {
+        if (actions) {
+            const uint32_t a = b.action[slot];
+            reinterpret_cast<int4*>(actions)[r] = make_int4(a & 255, (a >> 8) & 255, (a >> 16) & 255, a >> 24);
+        }
+        if (rewards) rewards[r] = b.reward[slot];
+        if (terminals) terminals[r] = b.terminal[slot];
+    }
+}
+
+// ------------------------------------------------------------------ exclusive scan of counts
+// One 1024-thread workgroup; each thread owns a contiguous chunk.  N = 65 536 -> 64 counts per
+// thread (256 KB read, 512 KB written): latency-, not bandwidth-bound, ~ a few microseconds.
+__global__ __launch_bounds__(1024) void k_scan(const int32_t* __restrict__ counts, int64_t* __restrict__ offsets,
+                                               int32_t* __restrict__ counts_out, int64_t N) {
+    __shared__ int64_t wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t chunk = (N + 1023) / 1024;
+    const int64_t lo = (int64_t)tid * chunk;
+    const int64_t hi = lo + chunk < N ? lo + chunk : N;
+    int64_t sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += counts[i];
+    int64_t inc = sum;                                       // inclusive scan across the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int64_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    int64_t run = base + inc - sum;
+    for (int64_t i = lo; i < hi; ++i) {
+        const int32_t c = counts[i];
+        offsets[i] = run;
+        if (counts_out) counts_out[i] = c;
+        run += c;
+    }
+    if (tid == 1023) offsets[N] = base + inc;
+}
+
+// ------------------------------------------------------------------ perspective stack write
+template <typename T> struct OutVal;
+template <> struct OutVal<float> { static __device__ __forceinline__ float of(unsigned b) { return (float)b; } };
+template <> struct OutVal<__half> { static __device__ __forceinline__ __half of(unsigned b) { return __ushort_as_half((unsigned short)(b ? 0x3C00 : 0)); } };
+struct bf16_t { unsigned short u; };
+template <> struct OutVal<bf16_t> { static __device__ __forceinline__ bf16_t of(unsigned b) { return bf16_t{(unsigned short)(b ? 0x3F80 : 0)}; } };
+template <> struct OutVal<uint8_t> { static __device__ __forceinline__ uint8_t of(unsigned b) { return (uint8_t)b; } };
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS ops of one wave execute in order; this only stops the compiler from moving LDS
+    // reads of other lanes' data above the writes (and drains lgkmcnt).
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// (hit, cell) -> source cell table, u8[NQ][NQ] (NQ <= 255 for d <= 11): filled once per handle.
+template <int D>
+__global__ void k_build_lut(uint8_t* __restrict__ lut) {
+    using L = Lat<D>;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L::NQ * L::NQ) return;
+    const int hit = t / L::NQ, cell = t - hit * L::NQ;
+    const int layer = hit >= L::DD, hrem = hit - layer * L::DD, i = hrem / D, j = hrem - i * D;
+    const int c = cell >= L::DD, crem = cell - c * L::DD, r = crem / D, s = crem - r * D;
+    lut[t] = (uint8_t)L::persp_src(layer, i, j, c, r, s);
+}
+
+// vp = V/P planes: V word k of lattice e at vp[(0*W+k)*N+e], P at vp[(1*W+k)*N+e].
+template <int D, typename OutT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restrict__ vp, int64_t N,
+                                                         const int64_t* __restrict__ offsets, OutT* __restrict__ out,
+                                                         int32_t* __restrict__ pos, int64_t capacity,
+                                                         const uint8_t* __restrict__ lut_g, int* __restrict__ err) {
+    using L = Lat<D>;
+    constexpr int DD = L::DD, NQ = L::NQ, W = L::W;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int VEC = 16 / (int)sizeof(OutT);              // elements per 16-byte lane store
+    constexpr int LUT_BYTES = (NQ * NQ + 15) & ~15;
+    constexpr int NQP = (NQ + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
+    __shared__ uint8_t cellv[WAVES][NQP];                    // syndrome cells (0/1) of the wave's lattice
+    __shared__ uint8_t hits[WAVES][NQP];                     // k-th hit -> flat qubit index
+
+    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
+        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
+    __syncthreads();
+
+    // the wave index is made provably uniform so that the lattice id, its plane words and its
+    // offset live in SGPRs (scalar loads) and the hit masks are computed on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    for (int64_t e = (int64_t)blockIdx.x * WAVES + wave; e < N; e += stride) {
+        typename L::B v, p, e0, e1;
+#pragma unroll
+        for (int k = 0; k < W; ++k) { v.w[k] = vp[(int64_t)k * N + e]; p.w[k] = vp[((int64_t)W + k) * N + e]; }
+        L::hit_masks(v, p, e0, e1);
+        const int n0 = e0.popc();
+        const int n = n0 + e1.popc();
+        const int64_t off = offsets[e];
+        if (off + n > capacity) { if (lane == 0) atomicOr(err, ERR_CAPACITY); continue; }
+
+        for (int c = lane; c < NQ; c += 64) {
+            const int l = c >= DD, bit = c - l * DD;
+            cellv[wave][c] = (uint8_t)(l ? p.get(bit) : v.get(bit));
+            const int is_hit = l ? e1.get(bit) : e0.get(bit);
+            if (is_hit) hits[wave][l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint8_t)c;
+        }
+        wave_lds_sync();
+
+        if (pos) {                                           // positions (P,3): (layer,row,col) of each hit
+            for (int k = lane; k < 3 * n; k += 64) {
+                const int hidx = k / 3, comp = k - 3 * hidx;
+                const int h = hits[wave][hidx];
+                const int l = h >= DD, rem = h - l * DD, row = rem / D, col = rem - row * D;
+                pos[off * 3 + k] = comp == 0 ? l : (comp == 1 ? row : col);
+            }
+        }
+
+        // the lattice's contiguous output segment [lo, hi) in elements, cut into 16-byte groups
+        const int total = n * NQ;
+        const int64_t lo = off * NQ;
+        const int64_t g_first = lo / VEC;
+        const int64_t g_last = (lo + total + VEC - 1) / VEC;
+        for (int64_t g = g_first + lane; g < g_last; g += 64) {
+            const int rel0 = (int)(g * VEC - lo);           // even; < 0 only for the first group
+            OutT vals[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; k += 2) {              // NQ and rel0 are even: a pair never straddles two perspectives
+                int rel = rel0 + k;
+                rel = rel < 0 ? 0 : (rel > total - 2 ? total - 2 : rel);
+                const int pidx = rel / NQ, cell = rel - pidx * NQ;
+                const int h = hits[wave][pidx];
+                const unsigned src2 = *reinterpret_cast<const unsigned short*>(&lut[h * NQ + cell]);
+                vals[k] = OutVal<OutT>::of(cellv[wave][src2 & 255]);
+                vals[k + 1] = OutVal<OutT>::of(cellv[wave][src2 >> 8]);
+            }
+            OutT* dst = out + g * VEC;
+            if (rel0 >= 0 && rel0 + VEC <= total) {
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(vals);
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    if (rel0 + k >= 0 && rel0 + k < total) dst[k] = vals[k];
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+// generateTransitionParallel on explicit u8 grids: one thread per output byte, the (hit, cell)
+// -> source-cell table does shift_state + rotate_state in one lookup; loads and stores coalesced.
+template <int D>
+__global__ __launch_bounds__(256) void k_states_transition(const uint8_t* __restrict__ st, const uint8_t* __restrict__ nst,
+                                                           const int32_t* __restrict__ actions, uint8_t* __restrict__ persp,
+                                                           uint8_t* __restrict__ next_persp, int32_t* __restrict__ actions_out,
+                                                           const uint8_t* __restrict__ lut, int64_t n, int* __restrict__ err) {
+    using L = Lat<D>;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * L::NQ) return;
+    const int64_t e = t / L::NQ;
+    const int c = (int)(t - e * L::NQ);
+    const int4 a = reinterpret_cast<const int4*>(actions)[e];
+    if (!action_ok<D>(a.x, a.y, a.z, a.w)) { if (c == 0) atomicOr(err, ERR_ACTION); return; }
+    const int src = lut[(a.x * L::DD + a.y * D + a.z) * L::NQ + c];
+    if (persp) persp[t] = st[e * L::NQ + src];
+    if (next_persp) next_persp[t] = nst[e * L::NQ + src];
+    if (c == 0 && actions_out) reinterpret_cast<int4*>(actions_out)[e] = make_int4(a.x, L::GS, L::GS, a.w);
+}
+
+// ------------------------------------------------------------------ epsilon-greedy selection
+// _selectActionBatch_prime (numba/util_actor.py:69-107): one wavefront per lattice.
+template <int D>
+__global__ __launch_bounds__(256) void k_select(const float* __restrict__ q, const int64_t* __restrict__ offsets,
+                                                const int32_t* __restrict__ pos, const double* __restrict__ eps,
+                                                const uint32_t* __restrict__ episodes, const uint32_t* __restrict__ steps,
+                                                int32_t* __restrict__ actions, float* __restrict__ qv, uint64_t seed,
+                                                int64_t first_env, int64_t N) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (e >= N) return;
+    const int64_t lo = offsets[e];
+    const int n = (int)(offsets[e + 1] - lo);
+    if (n == 0) {
+        if (lane < 4) actions[4 * e + lane] = 0;
+        if (qv && lane < 3) qv[3 * e + lane] = 0.f;
+        return;
+    }
+    const U4 w = draw(seed, (uint32_t)(first_env + e), episodes[e], steps[e], DOMAIN_SEL, 0);
+    const bool greedy = q != nullptr && (1.0 - eps[e]) > u01(w.x);
+    int pidx, a;
+    if (greedy) {
+        float best = -__builtin_inff();
+        int bk = 0x7fffffff;
+        for (int k = lane; k < 3 * n; k += 64) {
+            const float x = q[3 * lo + k];
+            if (x > best) { best = x; bk = k; }               // strict >: first maximum within the lane
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int ok = __shfl_xor(bk, o, 64);
+            if (ob > best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+        }
+        bk = bk == 0x7fffffff ? 0 : bk;
+        pidx = bk / 3; a = bk - 3 * pidx;
+    } else {
+        pidx = (int)mulhi32(w.y, (uint32_t)n);
+        a = (int)mulhi32(w.z, 3);
+    }
+    if (lane < 3) {
+        actions[4 * e + lane] = pos[3 * (lo + pidx) + lane];
+        if (qv) qv[3 * e + lane] = q ? q[3 * (lo + pidx) + lane] : 0.f;
+    }
+    if (lane == 3) actions[4 * e + 3] = a + 1;
+}
+
+}  // namespace tq

@@ -1,0 +1,284 @@
+// Bit-plane algebra of one toric-code lattice (d x d, two qubit layers).
+//
+// A d*d grid is one bitset of DD = d*d bits (bit r*d+c = cell (r,c)), W = ceil(DD/64)
+// 64-bit words.  A lattice is six such planes:
+//   x[0], x[1]   X-component of the Pauli on layer 0/1 qubits   (code 1 or 2)
+//   z[0], z[1]   Z-component                                    (code 2 or 3)
+//   v, p         vertex / plaquette syndrome  (state[0], state[1] of the reference)
+// Pauli codes I=0 X=1 Y=2 Z=3 (reference docs/toric_model.md:11); the Pauli product
+// mod phase is XOR of codes = XOR of (x,z) pairs (docs/toric_model.md:15).
+//
+// Geometry (reference src/util.py:68-69,77-78):
+//   v[i,j] = z0[i,j] ^ z0[i-1,j] ^ z1[i,j] ^ z1[i,j-1]
+//   p[i,j] = x0[i,j] ^ x0[i,j+1] ^ x1[i,j] ^ x1[i+1,j]
+// Defect-adjacent qubits (reference src/numba/util.py:48-52,62-66):
+//   E0[i,j] = v[i,j] | v[i+1,j] | p[i,j] | p[i,j-1]
+//   E1[i,j] = v[i,j] | v[i,j+1] | p[i,j] | p[i-1,j]
+//
+// Everything here is integer bit arithmetic, usable from host and device code.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TQ_HD __host__ __device__ __forceinline__
+#else
+#define TQ_HD inline
+#endif
+
+namespace tq {
+
+TQ_HD int popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+
+template <int W>
+struct Bits {
+    uint64_t w[W];
+
+    TQ_HD static Bits zero() { Bits b; for (int k = 0; k < W; ++k) b.w[k] = 0; return b; }
+    TQ_HD Bits operator|(const Bits& o) const { Bits r; for (int k = 0; k < W; ++k) r.w[k] = w[k] | o.w[k]; return r; }
+    TQ_HD Bits operator&(const Bits& o) const { Bits r; for (int k = 0; k < W; ++k) r.w[k] = w[k] & o.w[k]; return r; }
+    TQ_HD Bits operator^(const Bits& o) const { Bits r; for (int k = 0; k < W; ++k) r.w[k] = w[k] ^ o.w[k]; return r; }
+    TQ_HD bool any() const { uint64_t a = 0; for (int k = 0; k < W; ++k) a |= w[k]; return a != 0; }
+    TQ_HD int popc() const { int n = 0; for (int k = 0; k < W; ++k) n += popc64(w[k]); return n; }
+    TQ_HD int get(int i) const {
+        if (W == 1) return (int)((w[0] >> i) & 1);
+        uint64_t word = w[0];
+        for (int k = 1; k < W; ++k) word = ((i >> 6) == k) ? w[k] : word;   // select, no dynamic indexing
+        return (int)((word >> (i & 63)) & 1);
+    }
+    TQ_HD void flip(int i, int on) {
+        for (int k = 0; k < W; ++k) w[k] ^= (uint64_t)(on & ((i >> 6) == k)) << (i & 63);
+    }
+    // number of set bits strictly below position i
+    TQ_HD int rank(int i) const {
+        int n = 0;
+        for (int k = 0; k < W; ++k) {
+            int lim = i - 64 * k;                       // bits of word k below i
+            uint64_t m = lim >= 64 ? ~0ull : (lim <= 0 ? 0ull : ((1ull << lim) - 1));
+            n += popc64(w[k] & m);
+        }
+        return n;
+    }
+    // logical shifts by 0 <= s < 64*W.  Word indices stay compile-time (select chains) so a
+    // runtime shift never turns the word array into scratch memory on the GPU.
+    TQ_HD Bits shl(int s) const {
+        Bits r;
+        const int ws = s >> 6, bs = s & 63;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            uint64_t lo = 0, lo2 = 0;
+#pragma unroll
+            for (int j = 0; j <= k; ++j) {
+                lo = (ws == k - j) ? w[j] : lo;
+                lo2 = (ws == k - j - 1) ? w[j] : lo2;
+            }
+            r.w[k] = (lo << bs) | ((lo2 >> 1) >> (63 - bs));
+        }
+        return r;
+    }
+    TQ_HD Bits shr(int s) const {
+        Bits r;
+        const int ws = s >> 6, bs = s & 63;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            uint64_t hi = 0, hi2 = 0;
+#pragma unroll
+            for (int j = k; j < W; ++j) {
+                hi = (ws == j - k) ? w[j] : hi;
+                hi2 = (ws == j - k - 1) ? w[j] : hi2;
+            }
+            r.w[k] = (hi >> bs) | ((hi2 << 1) << (63 - bs));
+        }
+        return r;
+    }
+};
+
+template <int D>
+struct Lat {
+    static constexpr int DD = D * D;
+    static constexpr int NQ = 2 * DD;
+    static constexpr int W = (DD + 63) / 64;
+    static constexpr int GS = D / 2;                 // grid_shift = int(d/2) (Actor_mp.py:59)
+    using B = Bits<W>;
+
+    // mask with the DD valid bits set
+    TQ_HD static B full() {
+        B m;
+        for (int k = 0; k < W; ++k) {
+            int rem = DD - 64 * k;
+            m.w[k] = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1));
+        }
+        return m;
+    }
+    // mask whose every row holds the D-bit pattern `rowpat` (bit c of rowpat = column c);
+    // word index and shift amounts are compile-time after unrolling.
+    TQ_HD static B rows_of(uint64_t rowpat) {
+        B m;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            uint64_t acc = 0;
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                const int sh = r * D - 64 * k;             // position of row r inside word k
+                if (sh >= 0 && sh < 64) acc |= rowpat << sh;
+                else if (sh < 0 && sh > -D) acc |= rowpat >> (-sh);
+            }
+            m.w[k] = acc;
+        }
+        return m & full();
+    }
+    TQ_HD static B colmask(int c) { return rows_of(1ull << c); }
+    // mask of the columns [0, k)
+    TQ_HD static B lowcols(int k) { return rows_of((1ull << k) - 1); }
+
+    // out[r, c] = in[(r - k) mod D, c]   (np.roll(in, +k, axis=0)), 0 <= k < D
+    TQ_HD static B roll_rows(const B& a, int k) {
+        if (k == 0) return a;
+        return (a.shl(k * D) | a.shr(DD - k * D)) & full();
+    }
+    // out[r, c] = in[r, (c - k) mod D]   (np.roll(in, +k, axis=1)), 0 <= k < D
+    TQ_HD static B roll_cols(const B& a, int k) {
+        if (k == 0) return a;
+        B low = lowcols(k);                                    // destination columns [0,k) come from the wrap
+        B hi = full() ^ low;
+        return (a.shl(k) & hi) | (a.shr(D - k) & low);
+    }
+
+    struct State {        // one lattice
+        B x[2], z[2], v, p;
+    };
+
+    // createSyndromOpt (absent upstream; geometry as above)
+    TQ_HD static void syndrome(State& s) {
+        s.v = s.z[0] ^ roll_rows(s.z[0], 1) ^ s.z[1] ^ roll_cols(s.z[1], 1);
+        s.p = s.x[0] ^ roll_cols(s.x[0], D - 1) ^ s.x[1] ^ roll_rows(s.x[1], D - 1);
+    }
+    // defect-adjacent qubit masks E0 / E1 (numba/util.py:48-52,62-66)
+    TQ_HD static void hit_masks(const B& v, const B& p, B& e0, B& e1) {
+        e0 = v | roll_rows(v, D - 1) | p | roll_cols(p, 1);
+        e1 = v | roll_cols(v, D - 1) | p | roll_rows(p, 1);
+    }
+    TQ_HD static int persp_count(const B& v, const B& p) {
+        B e0, e1;
+        hit_masks(v, p, e0, e1);
+        return e0.popc() + e1.popc();
+    }
+    // env.step's qubit update: q[layer,row,col] ^= op  (op in 1..3)
+    TQ_HD static void apply(State& s, int layer, int row, int col, int op) {
+        const int i = row * D + col;
+        const int fx = (op == 1) | (op == 2), fz = (op >> 1) & 1;
+        s.x[0].flip(i, fx & (layer == 0));
+        s.x[1].flip(i, fx & (layer == 1));
+        s.z[0].flip(i, fz & (layer == 0));
+        s.z[1].flip(i, fz & (layer == 1));
+    }
+    TQ_HD static int code(const State& s, int layer, int i) {
+        const int x = layer ? s.x[1].get(i) : s.x[0].get(i);
+        const int z = layer ? s.z[1].get(i) : s.z[0].get(i);
+        return z ? (x ? 2 : 3) : x;                      // (x,z): (1,0)=X=1 (1,1)=Y=2 (0,1)=Z=3
+    }
+    // evalGroundState (theory): all four layer parities even
+    TQ_HD static int ground_state(const State& s) {
+        return !((s.x[0].popc() | s.x[1].popc() | s.z[0].popc() | s.z[1].popc()) & 1);
+    }
+
+    // Source cell (flat index into (2,d,d)) of output cell (c,r,s) of the perspective
+    // centred on hit (layer,i,j)  -- closed forms of SURVEY 8(a) A5/A6:
+    //   layer 0: P0[c,r,s] = state[c,(r+i-gs)%d,(s+j-gs)%d]
+    //   layer 1: P1[1,r,s] = state[1,(s+i-gs)%d,(d-1-r+j-gs)%d]
+    //            P1[0,r,s] = state[0,(s+i-gs)%d,((d-r)%d+j-gs)%d]
+    TQ_HD static int persp_src(int layer, int i, int j, int c, int r, int s) {
+        const int a = (i - GS + D) % D, b = (j - GS + D) % D;
+        int row, col;
+        if (layer == 0) { row = r; col = s; }
+        else { row = s; col = c ? (D - 1 - r) : (D - r) % D; }
+        return c * DD + ((row + a) % D) * D + (col + b) % D;
+    }
+
+    // The perspective of (v,p) centred on qubit (layer,i,j), as bit-planes
+    // (shift_state + rotate_state of util.py:87-102 in one pass).
+    TQ_HD static void perspective(const B& v, const B& p, int layer, int i, int j, B& ov, B& op) {
+        const int a = (GS - i + D) % D, b = (GS - j + D) % D;     // np.roll amounts
+        B rv = roll_cols(roll_rows(v, a), b);
+        B rp = roll_cols(roll_rows(p, a), b);
+        if (layer == 0) { ov = rv; op = rp; return; }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            uint64_t av = 0, ap = 0;
+            const int nb = (DD - 64 * k) < 64 ? (DD - 64 * k) : 64;
+            for (int bit = 0; bit < nb; ++bit) {
+                const int o = 64 * k + bit, r = o / D, s = o - r * D;
+                const int sp = s * D + (D - 1 - r);               // rot_p[r,s] = p[s,d-1-r]
+                const int sv = s * D + (r ? D - r : 0);           // rot_v[r,s] = v[s,(d-r)%d]
+                ap |= (uint64_t)rp.get(sp) << bit;
+                av |= (uint64_t)rv.get(sv) << bit;
+            }
+            ov.w[k] = av; op.w[k] = ap;
+        }
+    }
+};
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct U4 { uint32_t x, y, z, w; };
+
+TQ_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+TQ_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+enum : uint32_t { DOMAIN_ERR = 0, DOMAIN_SEL = 1, DOMAIN_PERR = 2 };
+constexpr int MAX_RESET_ROUNDS = 4096;
+
+TQ_HD U4 draw(uint64_t seed, uint32_t env, uint32_t episode, uint32_t round, uint32_t domain, uint32_t index) {
+    return philox4x32_10(env, episode, round, (domain << 24) | index, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+TQ_HD double u01(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
+
+// env.reset(p_error): depolarizing draw rounds until the syndrome is non-empty
+// (results/small_p_error_test.py:22-31,109-120).  RNG contract: oracle/toric_oracle.py.
+template <int D>
+TQ_HD int reset_lattice(typename Lat<D>::State& s, uint64_t seed, uint32_t env, uint32_t episode, double p) {
+    using L = Lat<D>;
+    int r = 0;
+    for (; r < MAX_RESET_ROUNDS; ++r) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            typename L::B x, z;
+#pragma unroll
+            for (int k = 0; k < L::W; ++k) {
+                uint64_t ax = 0, az = 0;
+                const int nb = (L::DD - 64 * k) < 64 ? (L::DD - 64 * k) : 64;
+                for (int bit = 0; bit < nb; ++bit) {
+                    const U4 w = draw(seed, env, episode, (uint32_t)r, DOMAIN_ERR,
+                                      (uint32_t)(l * L::DD + 64 * k + bit));
+                    const int err = u01(w.x) < p;
+                    const uint32_t pauli = 1 + mulhi32(w.y, 3);
+                    ax |= (uint64_t)(err & ((pauli == 1) | (pauli == 2))) << bit;
+                    az |= (uint64_t)(err & (int)(pauli >> 1)) << bit;
+                }
+                x.w[k] = ax; z.w[k] = az;
+            }
+            s.x[l] = x; s.z[l] = z;
+        }
+        L::syndrome(s);
+        if (s.v.any() || s.p.any()) return r + 1;
+    }
+    return r;
+}
+
+}  // namespace tq

@@ -1,0 +1,529 @@
+// libtoricenv: C-ABI over the HIP kernels (see include/toricenv.h for the contract and the
+// reference interfaces each entry point replaces).  gfx950 only; no CPU path: every entry
+// point needs a HIP device and reports TQ_E_HIP otherwise.
+#include "toricenv.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+
+#include "kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(TQ_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define KCHECK() HIPCHECK(hipGetLastError())
+
+constexpr int MAX_DEVICES = 16;
+constexpr int kSizes[] = {3, 5, 7, 9, 11};
+
+bool size_ok(int d) {
+    for (int s : kSizes) if (s == d) return true;
+    return false;
+}
+int size_slot(int d) { return (d - 3) / 2; }
+
+// per-device caches shared by handles and the stateless entry points
+struct DeviceCtx {
+    std::mutex mu;
+    uint8_t* lut[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* ws = nullptr;             // scratch of the stateless entry points
+    size_t ws_bytes = 0;
+    int num_cus = 0;
+};
+DeviceCtx g_ctx[MAX_DEVICES];
+
+inline dim3 grid1(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+#define DISPATCH_D(d, CALL)          \
+    switch (d) {                     \
+        case 3: CALL(3); break;      \
+        case 5: CALL(5); break;      \
+        case 7: CALL(7); break;      \
+        case 9: CALL(9); break;      \
+        case 11: CALL(11); break;    \
+        default: return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d); \
+    }
+
+int current_device(int* dev) {
+    HIPCHECK(hipGetDevice(dev));
+    if (*dev < 0 || *dev >= MAX_DEVICES) return fail(TQ_E_INVALID, "device %d out of range", *dev);
+    return TQ_OK;
+}
+
+int get_lut(int dev, int d, hipStream_t stream, const uint8_t** out) {
+    DeviceCtx& c = g_ctx[dev];
+    std::lock_guard<std::mutex> lock(c.mu);
+    const int slot = size_slot(d);
+    if (!c.lut[slot]) {
+        const int nq = 2 * d * d;
+        const size_t bytes = ((size_t)nq * nq + 15) & ~(size_t)15;
+        uint8_t* p = nullptr;
+        HIPCHECK(hipMalloc(&p, bytes));
+        HIPCHECK(hipMemsetAsync(p, 0, bytes, stream));
+#define CALL(D) hipLaunchKernelGGL(tq::k_build_lut<D>, grid1((int64_t)nq * nq, 256), dim3(256), 0, stream, p)
+        DISPATCH_D(d, CALL)
+#undef CALL
+        KCHECK();
+        HIPCHECK(hipStreamSynchronize(stream));     // once per (device, d)
+        c.lut[slot] = p;
+    }
+    if (!c.num_cus) {
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, dev));
+        c.num_cus = prop.multiProcessorCount;
+    }
+    *out = c.lut[slot];
+    return TQ_OK;
+}
+
+template <int D, typename OutT>
+int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
+                         int64_t capacity, const uint8_t* lut, int* err, int num_cus, hipStream_t stream) {
+    constexpr int THREADS = D <= 7 ? 256 : (D == 9 ? 512 : 1024);
+    constexpr int WAVES = THREADS / 64;
+    const int64_t want = (n + WAVES - 1) / WAVES;
+    const int64_t resident = (int64_t)num_cus * (2048 / THREADS);   // 32 waves per CU
+    const int64_t blocks = want < resident ? want : resident;
+    hipLaunchKernelGGL((tq::k_persp_write<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
+                       offsets, (OutT*)out, pos, capacity, lut, err);
+    KCHECK();
+    return TQ_OK;
+}
+
+template <int D>
+int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
+                       int64_t capacity, int dtype, const uint8_t* lut, int* err, int num_cus, hipStream_t stream) {
+    switch (dtype) {
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, lut, err, num_cus, stream);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, lut, err, num_cus, stream);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, lut, err, num_cus, stream);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, lut, err, num_cus, stream);
+        default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
+    }
+}
+
+}  // namespace
+
+struct tq_env {
+    int n, d, w, device;
+    uint64_t seed;
+    int64_t first_env;
+    double terminal_reward;
+    int max_steps;
+    tq::PerrSchedule sched;
+    uint64_t* planes;      // [6][W][N]
+    uint64_t* prev;        // [2][W][N]
+    uint32_t* episodes;
+    uint32_t* steps;
+    int32_t* counts;
+    double* p_roof;
+    int* err;              // device error latch
+    const uint8_t* lut;
+    int num_cus;
+};
+
+namespace {
+int check_handle(const tq_env* h) {
+    if (!h) return fail(TQ_E_INVALID, "NULL handle");
+    int dev;
+    if (int rc = current_device(&dev)) return rc;
+    if (dev != h->device) HIPCHECK(hipSetDevice(h->device));
+    return TQ_OK;
+}
+#define HANDLE(h)                                  \
+    if (int _rc = check_handle(h)) return _rc;     \
+    hipStream_t stream = (hipStream_t)stream_
+}  // namespace
+
+extern "C" {
+
+int tq_version(void) { return TQ_VERSION; }
+const char* tq_last_error(void) { return g_err; }
+
+int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_t first_env_id) {
+    if (!out) return fail(TQ_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_envs <= 0) return fail(TQ_E_INVALID, "n_envs must be > 0 (got %d)", n_envs);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (first_env_id < 0 || first_env_id + n_envs > 0xFFFFFFFFll)
+        return fail(TQ_E_INVALID, "global env ids must fit in 32 bits");
+    int ndev = 0;
+    HIPCHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev || device >= MAX_DEVICES)
+        return fail(TQ_E_INVALID, "device %d not available (%d HIP devices)", device, ndev);
+    HIPCHECK(hipSetDevice(device));
+    tq_env* h = new (std::nothrow) tq_env();
+    if (!h) return fail(TQ_E_INVALID, "out of host memory");
+    memset(h, 0, sizeof(*h));
+    h->n = n_envs; h->d = d; h->w = (d * d + 63) / 64; h->device = device;
+    h->seed = seed; h->first_env = first_env_id;
+    h->terminal_reward = 100.0; h->max_steps = 75;
+    h->sched = tq::PerrSchedule{TQ_PERR_FIXED, 0.1, 0.1, 0.1, 0.0};
+    const size_t N = (size_t)n_envs, W = (size_t)h->w;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); };
+    alloc((void**)&h->planes, 6 * W * N * 8);
+    alloc((void**)&h->prev, 2 * W * N * 8);
+    alloc((void**)&h->episodes, N * 4);
+    alloc((void**)&h->steps, N * 4);
+    alloc((void**)&h->counts, N * 4);
+    alloc((void**)&h->p_roof, N * 8);
+    alloc((void**)&h->err, 4);
+    if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
+    h->num_cus = g_ctx[device].num_cus;
+    *out = h;
+    return TQ_OK;
+}
+
+int tq_destroy(tq_env* h) {
+    if (!h) return TQ_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->planes); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
+    (void)hipFree(h->counts); (void)hipFree(h->p_roof); (void)hipFree(h->err);
+    delete h;
+    return TQ_OK;
+}
+
+int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int max_steps_per_episode) {
+    if (!h) return fail(TQ_E_INVALID, "NULL handle");
+    if (!(p_error_default >= 0.0 && p_error_default <= 1.0)) return fail(TQ_E_INVALID, "p_error must be in [0,1]");
+    if (max_steps_per_episode < 1) return fail(TQ_E_INVALID, "max_steps_per_episode must be >= 1");
+    h->sched.p_default = p_error_default;
+    h->terminal_reward = terminal_reward;
+    h->max_steps = max_steps_per_episode;
+    return TQ_OK;
+}
+
+int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_final, double p_delta) {
+    if (int rc = check_handle(h)) return rc;
+    if (strategy < TQ_PERR_FIXED || strategy > TQ_PERR_RANDOM) return fail(TQ_E_INVALID, "unknown p_error strategy %d", strategy);
+    h->sched.strategy = strategy; h->sched.p_start = p_start; h->sched.p_final = p_final; h->sched.p_delta = p_delta;
+    // env_p_errors = ones * p_start (Actor_mp.py:46)
+    double* host = new (std::nothrow) double[h->n];
+    if (!host) return fail(TQ_E_INVALID, "out of host memory");
+    for (int i = 0; i < h->n; ++i) host[i] = p_start;
+    hipError_t e = hipMemcpy(h->p_roof, host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice);
+    delete[] host;
+    HIPCHECK(e);
+    return TQ_OK;
+}
+
+int tq_num_envs(const tq_env* h) { return h ? h->n : 0; }
+int tq_size(const tq_env* h) { return h ? h->d : 0; }
+
+int tq_reset_all(tq_env* h, const double* p_err, void* stream_) {
+    HANDLE(h);
+#define CALL(D) hipLaunchKernelGGL(tq::k_reset<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->episodes, \
+        h->steps, h->counts, (const int32_t*)nullptr, 0, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_reset_idx(tq_env* h, const int32_t* idx, int n_idx, const double* p_err, void* stream_) {
+    HANDLE(h);
+    if (n_idx < 0 || (n_idx > 0 && !idx)) return fail(TQ_E_INVALID, "bad idx / n_idx");
+    if (n_idx == 0) return TQ_OK;
+#define CALL(D) hipLaunchKernelGGL(tq::k_reset<D>, grid1(n_idx, 256), dim3(256), 0, stream, h->planes, h->episodes, \
+        h->steps, h->counts, idx, n_idx, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_step(tq_env* h, const int32_t* actions, float* rewards, uint8_t* terminals, void* stream_) {
+    HANDLE(h);
+    if (!actions) return fail(TQ_E_INVALID, "actions is NULL");
+#define CALL(D) hipLaunchKernelGGL(tq::k_step<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->prev, actions, \
+        rewards, terminals, h->steps, h->counts, (float)h->terminal_reward, (int64_t)h->n, h->err)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_get_state(tq_env* h, uint8_t* out, void* stream_) {
+    HANDLE(h);
+    if (!out) return fail(TQ_E_INVALID, "out is NULL");
+    const int64_t total = (int64_t)h->n * 2 * h->d * h->d;
+#define CALL(D) hipLaunchKernelGGL(tq::k_get_state<D>, grid1(total, 256), dim3(256), 0, stream, h->planes, (int64_t)h->n, \
+        (const int32_t*)nullptr, (int64_t)h->n, out)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_get_state_idx(tq_env* h, const int32_t* idx, int n_idx, uint8_t* out, void* stream_) {
+    HANDLE(h);
+    if (n_idx < 0 || (n_idx > 0 && (!idx || !out))) return fail(TQ_E_INVALID, "bad idx / out");
+    if (n_idx == 0) return TQ_OK;
+    const int64_t total = (int64_t)n_idx * 2 * h->d * h->d;
+#define CALL(D) hipLaunchKernelGGL(tq::k_get_state<D>, grid1(total, 256), dim3(256), 0, stream, h->planes, (int64_t)h->n, \
+        idx, (int64_t)n_idx, out)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_get_qubits(tq_env* h, uint8_t* out, void* stream_) {
+    HANDLE(h);
+    if (!out) return fail(TQ_E_INVALID, "out is NULL");
+    const int64_t total = (int64_t)h->n * 2 * h->d * h->d;
+#define CALL(D) hipLaunchKernelGGL(tq::k_get_qubits<D>, grid1(total, 256), dim3(256), 0, stream, h->planes, (int64_t)h->n, out)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_set_qubits(tq_env* h, const uint8_t* qubits, void* stream_) {
+    HANDLE(h);
+    if (!qubits) return fail(TQ_E_INVALID, "qubits is NULL");
+#define CALL(D) hipLaunchKernelGGL(tq::k_set_qubits<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->counts, qubits, (int64_t)h->n)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_get_counters(tq_env* h, uint32_t* episodes, uint32_t* steps, void* stream_) {
+    HANDLE(h);
+    if (episodes) HIPCHECK(hipMemcpyAsync(episodes, h->episodes, 4 * (size_t)h->n, hipMemcpyDeviceToDevice, stream));
+    if (steps) HIPCHECK(hipMemcpyAsync(steps, h->steps, 4 * (size_t)h->n, hipMemcpyDeviceToDevice, stream));
+    return TQ_OK;
+}
+
+int tq_eval_ground_state(tq_env* h, uint8_t* out, void* stream_) {
+    HANDLE(h);
+    if (!out) return fail(TQ_E_INVALID, "out is NULL");
+#define CALL(D) hipLaunchKernelGGL(tq::k_flags<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, (int64_t)h->n, out, (uint8_t*)nullptr)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_is_terminal(tq_env* h, uint8_t* out, void* stream_) {
+    HANDLE(h);
+    if (!out) return fail(TQ_E_INVALID, "out is NULL");
+#define CALL(D) hipLaunchKernelGGL(tq::k_flags<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, (int64_t)h->n, (uint8_t*)nullptr, out)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream_) {
+    HANDLE(h);
+    if (!offsets) return fail(TQ_E_INVALID, "offsets is NULL");
+    hipLaunchKernelGGL(tq::k_scan, dim3(1), dim3(1024), 0, stream, h->counts, offsets, counts, (int64_t)h->n);
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positions, int64_t capacity,
+                   int dtype, void* stream_) {
+    HANDLE(h);
+    if (!offsets || !out) return fail(TQ_E_INVALID, "offsets / out is NULL");
+    if (capacity < 0) return fail(TQ_E_INVALID, "negative capacity");
+    const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->lut, h->err, h->num_cus, stream)) return rc
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    return TQ_OK;
+}
+
+// ---- stateless variants (states outside a handle) -------------------------------------------
+static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int** err) {
+    DeviceCtx& c = g_ctx[dev];
+    std::lock_guard<std::mutex> lock(c.mu);
+    const size_t w = (size_t)(d * d + 63) / 64;
+    const size_t need = 2 * w * (size_t)n * 8 + (((size_t)n * 4 + 15) & ~(size_t)15) + 16;
+    if (c.ws_bytes < need) {
+        if (c.ws) HIPCHECK(hipFree(c.ws));
+        c.ws = nullptr; c.ws_bytes = 0;
+        HIPCHECK(hipMalloc(&c.ws, need));
+        HIPCHECK(hipMemset(c.ws, 0, need));
+        c.ws_bytes = need;
+    }
+    *vp = (uint64_t*)c.ws;
+    *counts = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8);
+    *err = (int*)((char*)c.ws + need - 16);
+    return TQ_OK;
+}
+
+int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, int64_t* offsets, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (n <= 0 || !states || !offsets) return fail(TQ_E_INVALID, "bad n / states / offsets");
+    int dev;
+    if (int rc = current_device(&dev)) return rc;
+    uint64_t* vp; int32_t* cnt; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &err)) return rc;
+#define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, cnt, (int64_t)n)
+    DISPATCH_D(d, CALL)
+#undef CALL
+    KCHECK();
+    hipLaunchKernelGGL(tq::k_scan, dim3(1), dim3(1024), 0, stream, cnt, offsets, counts, (int64_t)n);
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* offsets, void* out,
+                          int32_t* positions, int64_t capacity, int dtype, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (n <= 0 || !states || !offsets || !out || capacity < 0) return fail(TQ_E_INVALID, "bad arguments");
+    int dev;
+    if (int rc = current_device(&dev)) return rc;
+    const uint8_t* lut;
+    if (int rc = get_lut(dev, d, stream, &lut)) return rc;
+    uint64_t* vp; int32_t* cnt; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &err)) return rc;
+#define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, (int32_t*)nullptr, (int64_t)n)
+    DISPATCH_D(d, CALL)
+#undef CALL
+    KCHECK();
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, lut, err, g_ctx[dev].num_cus, stream)) return rc
+    DISPATCH_D(d, CALL)
+#undef CALL
+    return TQ_OK;
+}
+
+int tq_states_transition(int d, int n, const uint8_t* states, const uint8_t* next_states, const int32_t* actions,
+                         uint8_t* persp, uint8_t* next_persp, int32_t* actions_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (n <= 0 || !actions || (persp && !states) || (next_persp && !next_states)) return fail(TQ_E_INVALID, "bad arguments");
+    int dev;
+    if (int rc = current_device(&dev)) return rc;
+    const uint8_t* lut;
+    if (int rc = get_lut(dev, d, stream, &lut)) return rc;
+    uint64_t* vp; int32_t* cnt; int* err;
+    if (int rc = states_scratch(dev, d, 1, &vp, &cnt, &err)) return rc;
+    const int64_t total = (int64_t)n * 2 * d * d;
+#define CALL(D) hipLaunchKernelGGL(tq::k_states_transition<D>, grid1(total, 256), dim3(256), 0, stream, states, next_states, \
+        actions, persp, next_persp, actions_out, lut, (int64_t)n, err)
+    DISPATCH_D(d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_select_action(tq_env* h, const float* q_table, const int64_t* offsets, const int32_t* positions,
+                     const double* eps, int32_t* actions, float* q_values, void* stream_) {
+    HANDLE(h);
+    if (!offsets || !positions || !actions) return fail(TQ_E_INVALID, "offsets / positions / actions is NULL");
+    if (q_table && !eps) return fail(TQ_E_INVALID, "eps is NULL");
+#define CALL(D) hipLaunchKernelGGL(tq::k_select<D>, grid1((int64_t)h->n * 64, 256), dim3(256), 0, stream, q_table, offsets, \
+        positions, eps, h->episodes, h->steps, actions, q_values, h->seed, h->first_env, (int64_t)h->n)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int64_t tq_transition_block_bytes(int d, int64_t cap) {
+    if (!size_ok(d) || cap < 0) return -1;
+    return tq::block_bytes((d * d + 63) / 64, cap);
+}
+
+// scratch block of the handle-less tq_transition_write path lives in the stateless workspace
+int tq_transition_write(tq_env* h, const int32_t* actions, uint8_t* persp, uint8_t* next_persp,
+                        int32_t* actions_out, void* stream_) {
+    HANDLE(h);
+    if (!actions) return fail(TQ_E_INVALID, "actions is NULL");
+    DeviceCtx& c = g_ctx[h->device];
+    void* blk = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        const size_t need = (size_t)tq::block_bytes(h->w, h->n);
+        if (c.ws_bytes < need) {
+            if (c.ws) HIPCHECK(hipFree(c.ws));
+            c.ws = nullptr; c.ws_bytes = 0;
+            HIPCHECK(hipMalloc(&c.ws, need));
+            c.ws_bytes = need;
+        }
+        blk = c.ws;
+    }
+    tq::BlockView b = tq::block_view(blk, h->w, h->n);
+#define CALL(D) hipLaunchKernelGGL(tq::k_transition<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->prev, actions, \
+        b, (int64_t)0, (int64_t)h->n, h->err)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return tq_transition_unpack(h->d, blk, h->n, 0, h->n, persp, next_persp, actions_out, nullptr, nullptr, stream_);
+}
+
+int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, int64_t count, uint8_t* persp,
+                         uint8_t* next_persp, int32_t* actions, float* rewards, uint8_t* terminals, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!block || first < 0 || count < 0 || first + count > cap) return fail(TQ_E_INVALID, "bad block / slot range");
+    if (count == 0) return TQ_OK;
+    tq::BlockView b = tq::block_view(const_cast<void*>(block), (d * d + 63) / 64, cap);
+    const int64_t total = count * 2 * d * d;
+#define CALL(D) hipLaunchKernelGGL(tq::k_block_unpack<D>, grid1(total, 256), dim3(256), 0, stream, b, first, count, persp, \
+        next_persp, actions, rewards, terminals)
+    DISPATCH_D(d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_actor_step(tq_env* h, const int32_t* actions, int32_t* actions_out, float* rewards, uint8_t* terminals,
+                  void* block, int64_t block_cap, int64_t slot_base, void* stream_) {
+    HANDLE(h);
+    tq::BlockView b;
+    memset(&b, 0, sizeof(b));
+    if (block) {
+        if (slot_base < 0 || slot_base + h->n > block_cap) return fail(TQ_E_CAPACITY, "transition block too small");
+        b = tq::block_view(block, h->w, block_cap);
+    }
+#define CALL(D) hipLaunchKernelGGL(tq::k_actor_step<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->episodes, \
+        h->steps, h->counts, h->p_roof, actions, actions_out, rewards, terminals, b, block ? 1 : 0, slot_base, h->sched, \
+        (float)h->terminal_reward, h->max_steps, h->seed, h->first_env, (int64_t)h->n, h->err)
+    DISPATCH_D(h->d, CALL)
+#undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_check(tq_env* h, void* stream_) {
+    HANDLE(h);
+    int flag = 0;
+    HIPCHECK(hipMemcpyAsync(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    if (flag) HIPCHECK(hipMemsetAsync(h->err, 0, sizeof(int), stream));
+    if (flag & tq::ERR_ACTION) return fail(TQ_E_ACTION, "an action outside the lattice or with op not in 1..3 was applied");
+    if (flag & tq::ERR_CAPACITY) return fail(TQ_E_CAPACITY, "perspective stack capacity exceeded");
+    return TQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+"""Host-side mirror of the reference's env surface over libtoricenv (HIP).
+
+Replaces, with the same names / argument order / return shapes:
+  * ``gym.make('toric-code-v0', config=...)``  -> :func:`make` / :class:`ToricEnv`
+    (gym_ToricCode is an absent submodule upstream; API census in SURVEY.md 8(b))
+  * ``src/EnvSet.py:4-51``                      -> :class:`EnvSet`
+  * ``generatePerspectiveBatch`` + concatenate (``src/numba/util_actor.py:33-39,56-67``)
+                                                -> :meth:`EnvSet.generatePerspective`
+  * ``_selectActionBatch_prime`` (``src/numba/util_actor.py:69-107``) -> :meth:`EnvSet.selectAction`
+  * ``generateTransitionParallel`` (``src/util_actor.py:223-264``)    -> :meth:`EnvSet.generateTransition`
+  * the body of the actor loop after the policy (``src/Actor_mp.py:116-183``) -> :meth:`EnvSet.actorStep`
+
+PyTorch-ROCm is only the device-memory container and stream provider; all lattice work
+happens in the HIP kernels behind the C-ABI.  With ``numpy_io=True`` (default) the methods
+take/return numpy arrays with the reference's dtypes, so ``Actor_mp``-style loops run
+unchanged; with ``numpy_io=False`` they take/return device tensors and never synchronise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import TQ_BF16, TQ_F16, TQ_F32, TQ_U8, check
+
+_DTYPES = {torch.float32: TQ_F32, torch.float16: TQ_F16, torch.bfloat16: TQ_BF16, torch.uint8: TQ_U8}
+_STRATEGY = {None: 0, "fixed": 0, "linear": 1, "random": 2}
+SUPPORTED_SIZES = (3, 5, 7, 9, 11)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise _lib.ToricEnvError("no HIP device visible to PyTorch-ROCm: the toric env has no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError(f"device must be a cuda (ROCm) device, got {dev}")
+    return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+class _ActionSpace:
+    """``env.action_space.high[-1] == 3`` (Actor_mp.py:58)."""
+
+    def __init__(self, d):
+        self.low = np.array([0, 0, 0, 1])
+        self.high = np.array([1, d - 1, d - 1, 3])
+
+
+class ToricEnv:
+    """Single-lattice facade with the attributes the reference touches on a gym env:
+    system_size, action_space, reset, step, qubit_matrix, state, createSyndromOpt,
+    isTerminalState, evalGroundState.  Backed by an EnvSet of one lattice on the GPU,
+    created on first use."""
+
+    def __init__(self, config=None, device=None, seed=0):
+        config = dict(config or {})
+        self.config = config
+        self.system_size = int(config.get("size", 3))
+        if self.system_size not in SUPPORTED_SIZES:
+            raise ValueError(f"size must be odd in {SUPPORTED_SIZES}, got {self.system_size}")
+        if int(config.get("min_qubit_errors", 0)) != 0:
+            raise ValueError("min_qubit_errors != 0 is not supported (always 0 upstream: Distributed_mp.py:74)")
+        self.p_error = float(config.get("p_error", 0.1))
+        self.terminal_reward = float(config.get("terminal_reward", 100.0))
+        self.action_space = _ActionSpace(self.system_size)
+        self.device = device
+        self.seed = int(seed)
+        self._set = None
+
+    def _envs(self):
+        if self._set is None:
+            self._set = EnvSet(self, 1, device=self.device, seed=self.seed)
+        return self._set
+
+    def reset(self, p_error=None):
+        return self._envs().resetAll(None if p_error is None else [p_error])[0]
+
+    def step(self, action):
+        s, r, t, info = self._envs().step(np.asarray(action).reshape(1, 4))
+        return s[0], float(r[0]), bool(t[0]), info
+
+    @property
+    def state(self):
+        return self._envs().getStates()[0]
+
+    @property
+    def qubit_matrix(self):
+        return self._envs().getQubits()[0]
+
+    @qubit_matrix.setter
+    def qubit_matrix(self, q):
+        self._envs().setQubits(np.asarray(q).reshape(1, 2, self.system_size, self.system_size))
+
+    def createSyndromOpt(self, qubit_matrix):
+        d = self.system_size
+        scratch = EnvSet(self, 1, device=self.device, seed=self.seed)
+        scratch.setQubits(np.asarray(qubit_matrix).reshape(1, 2, d, d))
+        return scratch.getStates()[0]
+
+    @staticmethod
+    def isTerminalState(state):
+        return bool(np.all(np.asarray(state) == 0))
+
+    def evalGroundState(self):
+        return bool(self._envs().evalGroundState()[0])
+
+
+def make(env_id, config=None, device=None, seed=0):
+    """Stand-in for ``gym.make('toric-code-v0', config=...)`` (Distributed_mp.py:72-76)."""
+    if env_id != "toric-code-v0":
+        raise ValueError(f"unknown env id {env_id!r} (only 'toric-code-v0')")
+    return ToricEnv(config, device=device, seed=seed)
+
+
+class TransitionBlock:
+    """Packed transition block on the device (layout: include/toricenv.h)."""
+
+    def __init__(self, d, capacity, device):
+        self.d, self.capacity = int(d), int(capacity)
+        nbytes = _lib.load().tq_transition_block_bytes(self.d, self.capacity)
+        if nbytes < 0:
+            raise ValueError("bad transition block shape")
+        self.buf = torch.zeros(max(int(nbytes), 8), dtype=torch.uint8, device=device)
+
+    @property
+    def nbytes(self):
+        return int(self.buf.numel())
+
+    def unpack(self, first=0, count=None, buf=None):
+        """-> dict of device tensors (perspective u8, next_perspective u8, action i32[n,4],
+        reward f32, terminal u8) for slots [first, first+count)."""
+        buf = self.buf if buf is None else buf
+        count = self.capacity - first if count is None else int(count)
+        d, dev = self.d, buf.device
+        out = dict(perspective=torch.empty((count, 2, d, d), dtype=torch.uint8, device=dev),
+                   next_perspective=torch.empty((count, 2, d, d), dtype=torch.uint8, device=dev),
+                   action=torch.empty((count, 4), dtype=torch.int32, device=dev),
+                   reward=torch.empty(count, dtype=torch.float32, device=dev),
+                   terminal=torch.empty(count, dtype=torch.uint8, device=dev))
+        with torch.cuda.device(dev):
+            check(_lib.load().tq_transition_unpack(d, _ptr(buf), self.capacity, int(first), count,
+                                                   _ptr(out["perspective"]), _ptr(out["next_perspective"]),
+                                                   _ptr(out["action"]), _ptr(out["reward"]),
+                                                   _ptr(out["terminal"]), _stream()))
+        return out
+
+
+def transition_dtype(size):
+    """The reference's replay record (Actor_mp.py:52-56, util.py:10)."""
+    action_type = np.dtype([('position', (np.int64, 3)), ('op', np.int64)])
+    return np.dtype([('perspective', (np.int64, (2, size, size))), ('action', action_type),
+                     ('reward', np.float64), ('next_perspective', (np.int64, (2, size, size))),
+                     ('terminal', np.bool_)])
+
+
+def to_structured(unpacked, size):
+    """dict from TransitionBlock.unpack / generateTransition -> numpy array of transition_dtype."""
+    n = unpacked["perspective"].shape[0]
+    rec = np.empty(n, dtype=transition_dtype(size))
+    get = lambda k: unpacked[k].cpu().numpy() if torch.is_tensor(unpacked[k]) else np.asarray(unpacked[k])
+    a = get("action")
+    rec['perspective'] = get("perspective")
+    rec['next_perspective'] = get("next_perspective")
+    rec['action']['position'] = a[:, :3]
+    rec['action']['op'] = a[:, 3]
+    rec['reward'] = get("reward")
+    rec['terminal'] = get("terminal").astype(bool)
+    return rec
+
+
+class EnvSet:
+    """Batch of N toric-code lattices resident on one MI355X (reference: src/EnvSet.py:4-51).
+
+    ``env`` is a :class:`ToricEnv` (or anything with ``system_size`` and optionally
+    ``p_error`` / ``terminal_reward``).  ``first_env_id`` is the shard offset of this handle's
+    lattices in the global env numbering (RNG is keyed by global id, so any partition over
+    GPUs yields identical lattices).
+    """
+
+    def __init__(self, env, no_envs, device=None, seed=None, first_env_id=0, numpy_io=True,
+                 max_steps_per_episode=75):
+        self._h = C.c_void_p(None)
+        self.size = int(env.system_size)
+        self.no_envs = int(no_envs)
+        self.numpy_io = bool(numpy_io)
+        self.device = _require_gpu(device if device is not None else getattr(env, "device", None))
+        self.seed = int(getattr(env, "seed", 0) if seed is None else seed)
+        self.first_env_id = int(first_env_id)
+        self.p_error = float(getattr(env, "p_error", 0.1))
+        self.terminal_reward = float(getattr(env, "terminal_reward", 100.0))
+        self.max_steps_per_episode = int(max_steps_per_episode)
+        self._L = _lib.load()
+        with torch.cuda.device(self.device):
+            check(self._L.tq_create(C.byref(self._h), self.no_envs, self.size, self.device.index,
+                                    C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), self.first_env_id))
+        check(self._L.tq_set_params(self._h, self.p_error, self.terminal_reward, self.max_steps_per_episode))
+        n, d, dev = self.no_envs, self.size, self.device
+        self._state_u8 = torch.zeros((n, 2, d, d), dtype=torch.uint8, device=dev)
+        self._rewards = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._terminals = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._actions = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        self._qv = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+        self._counts = torch.zeros(n, dtype=torch.int32, device=dev)
+        self._offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        self._positions = None
+        # attributes of the reference class (EnvSet.py:9-11)
+        self.states = np.zeros((n, 2, d, d), dtype=np.int64)
+        self.rewards = np.zeros(n)
+        self.terminals = np.zeros(n, dtype=bool)
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.tq_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, fn, *args):
+        with torch.cuda.device(self.device):
+            check(fn(self._h, *args, _stream()))
+
+    def _dev(self, x, dtype):
+        if x is None:
+            return None
+        if torch.is_tensor(x):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x), device=self.device).to(dtype).contiguous()
+
+    def check(self):
+        """Raise if a kernel latched an error (bad action / capacity).  Synchronises."""
+        self._call(self._L.tq_check)
+
+    def set_perror_schedule(self, strategy, p_start, p_final, p_delta):
+        """Reset policy of the actor (Actor_mp.py:41-46,176-180) used by actorStep."""
+        with torch.cuda.device(self.device):
+            check(self._L.tq_set_perror_schedule(self._h, _STRATEGY[strategy], float(p_start), float(p_final),
+                                                 float(p_delta)))
+
+    # ------------------------------------------------------------------ reference surface
+    def resetAll(self, p_errors=None):
+        """EnvSet.py:29-36 -> states (N,2,d,d) (int64 numpy / uint8 tensor)."""
+        p = self._dev(p_errors, torch.float64)
+        if p is not None and p.numel() != self.no_envs:
+            raise ValueError("p_errors must have one entry per env")
+        self._call(self._L.tq_reset_all, _ptr(p))
+        return self._return_states()
+
+    def resetTerminalEnvs(self, idx, p_errors=None):
+        """EnvSet.py:19-27 -> states of the reset lattices (len(idx),2,d,d) (float64 numpy)."""
+        idx_t = self._dev(idx, torch.int32)
+        k = int(idx_t.numel())
+        p = self._dev(p_errors, torch.float64)
+        if p is not None and p.numel() != k:
+            raise ValueError("p_errors must have one entry per idx")
+        if self.numpy_io and k:
+            idx_np = idx_t.cpu().numpy()
+            if idx_np.min() < 0 or idx_np.max() >= self.no_envs or np.unique(idx_np).size != k:
+                raise ValueError("idx must be distinct env indices in range")
+        out = torch.empty((k, 2, self.size, self.size), dtype=torch.uint8, device=self.device)
+        if k:
+            self._call(self._L.tq_reset_idx, _ptr(idx_t), k, _ptr(p))
+            self._call(self._L.tq_get_state_idx, _ptr(idx_t), k, _ptr(out))
+        return out.cpu().numpy().astype(np.float64) if self.numpy_io else out
+
+    def step(self, actions):
+        """EnvSet.py:38-47 -> (states, rewards, terminals, info)."""
+        a = self._dev(actions, torch.int32)
+        if a.numel() != 4 * self.no_envs:
+            raise ValueError("actions must be (no_envs, 4)")
+        self._actions.copy_(a.reshape(self.no_envs, 4))
+        self._call(self._L.tq_step, _ptr(self._actions), _ptr(self._rewards), _ptr(self._terminals))
+        states = self._return_states()
+        if self.numpy_io:
+            self.check()
+            self.rewards = self._rewards.cpu().numpy().astype(np.float64)
+            self.terminals = self._terminals.cpu().numpy().astype(bool)
+            return states, self.rewards, self.terminals, {}
+        return states, self._rewards, self._terminals, {}
+
+    def _return_states(self):
+        self._call(self._L.tq_get_state, _ptr(self._state_u8))
+        if self.numpy_io:
+            self.states = self._state_u8.cpu().numpy().astype(np.int64)
+            return self.states
+        return self._state_u8
+
+    def getStates(self):
+        return self._return_states()
+
+    def getQubits(self):
+        q = torch.empty((self.no_envs, 2, self.size, self.size), dtype=torch.uint8, device=self.device)
+        self._call(self._L.tq_get_qubits, _ptr(q))
+        return q.cpu().numpy().astype(np.int64) if self.numpy_io else q
+
+    def setQubits(self, qubits):
+        q = self._dev(qubits, torch.uint8)
+        if q.numel() != self.no_envs * 2 * self.size * self.size:
+            raise ValueError("qubits must be (no_envs, 2, d, d)")
+        self._call(self._L.tq_set_qubits, _ptr(q))
+
+    def getCounters(self):
+        ep = torch.empty(self.no_envs, dtype=torch.int32, device=self.device)
+        st = torch.empty(self.no_envs, dtype=torch.int32, device=self.device)
+        self._call(self._L.tq_get_counters, _ptr(ep), _ptr(st))
+        return (ep.cpu().numpy(), st.cpu().numpy()) if self.numpy_io else (ep, st)
+
+    def evalGroundState(self):
+        out = torch.empty(self.no_envs, dtype=torch.uint8, device=self.device)
+        self._call(self._L.tq_eval_ground_state, _ptr(out))
+        return out.cpu().numpy().astype(bool) if self.numpy_io else out
+
+    def isTerminal(self):
+        out = torch.empty(self.no_envs, dtype=torch.uint8, device=self.device)
+        self._call(self._L.tq_is_terminal, _ptr(out))
+        return out.cpu().numpy().astype(bool) if self.numpy_io else out
+
+    # ------------------------------------------------------------------ perspectives
+    def perspectiveCounts(self):
+        """-> (counts i32[N], offsets i64[N+1]) device tensors; no synchronisation."""
+        self._call(self._L.tq_persp_count, _ptr(self._counts), _ptr(self._offsets))
+        return self._counts, self._offsets
+
+    def writePerspectives(self, out, positions=None, offsets=None):
+        """Write the stack for ``offsets`` (default: the last perspectiveCounts) into the
+        caller's tensor ``out`` (capacity = out.shape[0] perspectives).  No synchronisation."""
+        if out.dtype not in _DTYPES or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32/float16/bfloat16/uint8 tensor")
+        nq = 2 * self.size * self.size
+        cap = out.numel() // nq
+        if positions is not None and (positions.dtype != torch.int32 or positions.numel() < 3 * cap):
+            raise ValueError("positions must be int32 with at least 3*capacity elements")
+        off = self._offsets if offsets is None else offsets
+        self._call(self._L.tq_persp_write, _ptr(off), _ptr(out), _ptr(positions), cap, _DTYPES[out.dtype])
+        self._positions = positions
+
+    def generatePerspective(self, dtype=torch.float32):
+        """generatePerspectiveBatch + concatenate for the current states
+        (numba/util_actor.py:33-39,56-67) -> (perspectives (P,2,d,d), positions (P,3), counts (N,)).
+        Reads P back from the device (one 8-byte copy), like the reference's data-dependent shape."""
+        counts, offsets = self.perspectiveCounts()
+        P = int(offsets[-1].item())
+        d = self.size
+        out = torch.empty((P, 2, d, d), dtype=dtype, device=self.device)
+        pos = torch.empty((P, 3), dtype=torch.int32, device=self.device)
+        if P:
+            self.writePerspectives(out, pos, offsets)
+        self._positions = pos
+        if self.numpy_io:
+            return out.cpu().numpy(), pos.cpu().numpy().astype(np.int64), counts.cpu().numpy().astype(np.int64)
+        return out, pos, counts
+
+    # ------------------------------------------------------------------ policy glue
+    def selectAction(self, q_table, eps, positions=None, offsets=None):
+        """_selectActionBatch_prime on the device -> (actions (N,4), q_values (N,3)).
+        q_table None = pure exploration (every eps must be 1)."""
+        pos = self._positions if positions is None else positions
+        if pos is None:
+            raise ValueError("call generatePerspective / writePerspectives (with positions) first")
+        pos = self._dev(pos, torch.int32)
+        off = self._offsets if offsets is None else self._dev(offsets, torch.int64)
+        q = self._dev(q_table, torch.float32)
+        e = None
+        if q is not None:
+            e = self._dev(np.broadcast_to(np.asarray(eps, np.float64), (self.no_envs,)) if not torch.is_tensor(eps) else eps,
+                          torch.float64)
+        self._call(self._L.tq_select_action, _ptr(q), _ptr(off), _ptr(pos), _ptr(e), _ptr(self._actions), _ptr(self._qv))
+        if self.numpy_io:
+            return self._actions.cpu().numpy().astype(np.int64), self._qv.cpu().numpy()
+        return self._actions, self._qv
+
+    def generateTransition(self, actions):
+        """generateTransitionParallel for the last step() (util_actor.py:223-264)
+        -> dict(perspective u8, next_perspective u8, action i32[N,4]) of device tensors
+        (numpy arrays with numpy_io)."""
+        a = self._dev(actions, torch.int32)
+        n, d, dev = self.no_envs, self.size, self.device
+        out = dict(perspective=torch.empty((n, 2, d, d), dtype=torch.uint8, device=dev),
+                   next_perspective=torch.empty((n, 2, d, d), dtype=torch.uint8, device=dev),
+                   action=torch.empty((n, 4), dtype=torch.int32, device=dev))
+        self._call(self._L.tq_transition_write, _ptr(a), _ptr(out["perspective"]), _ptr(out["next_perspective"]),
+                   _ptr(out["action"]))
+        if self.numpy_io:
+            self.check()
+            return {k: v.cpu().numpy() for k, v in out.items()}
+        return out
+
+    def newTransitionBlock(self, steps=1):
+        return TransitionBlock(self.size, self.no_envs * int(steps), self.device)
+
+    def actorStep(self, actions=None, block=None, slot=0, want_actions=True):
+        """Fused step -> transition -> auto-reset -> counts (Actor_mp.py:116-183).
+        actions None = pure exploration drawn in-kernel.  ``block``/``slot``: lattice e writes
+        transition slot ``slot*no_envs + e`` of the TransitionBlock.
+        -> (actions_taken i32[N,4], rewards f32[N], terminals u8[N]) device tensors."""
+        a = self._dev(actions, torch.int32)
+        blk_ptr, cap, base = C.c_void_p(0), 0, 0
+        if block is not None:
+            blk_ptr, cap, base = _ptr(block.buf), block.capacity, int(slot) * self.no_envs
+        self._call(self._L.tq_actor_step, _ptr(a), _ptr(self._actions) if want_actions else C.c_void_p(0),
+                   _ptr(self._rewards), _ptr(self._terminals), blk_ptr, cap, base)
+        if self.numpy_io:
+            self.check()
+            return (self._actions.cpu().numpy().astype(np.int64), self._rewards.cpu().numpy().astype(np.float64),
+                    self._terminals.cpu().numpy().astype(bool))
+        return self._actions, self._rewards, self._terminals
+
+
+def generatePerspectiveBatch(grid_shift, toric_size, states, dtype=torch.float32, device=None):
+    """numba/util_actor.py:56-67 for syndromes that do not live in an EnvSet (e.g. the learner's
+    next_state batch, util_learner.py:48-111).  states: (n,2,d,d) numpy / tensor.
+    -> (perspectives (P,2,d,d) tensor, positions (P,3) i32 tensor, counts (n,) i32 tensor)."""
+    dev = _require_gpu(device)
+    if int(grid_shift) != int(toric_size) // 2:
+        raise ValueError("grid_shift must be int(toric_size/2) (Actor_mp.py:59)")
+    L = _lib.load()
+    st = states if torch.is_tensor(states) else torch.as_tensor(np.ascontiguousarray(states))
+    st = st.to(device=dev, dtype=torch.uint8).contiguous()
+    n, d = int(st.shape[0]), int(toric_size)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(L.tq_states_persp_count(d, n, _ptr(st), _ptr(counts), _ptr(offsets), _stream()))
+        P = int(offsets[-1].item())
+        out = torch.empty((P, 2, d, d), dtype=dtype, device=dev)
+        pos = torch.empty((P, 3), dtype=torch.int32, device=dev)
+        if P:
+            check(L.tq_states_persp_write(d, n, _ptr(st), _ptr(offsets), _ptr(out), _ptr(pos), P, _DTYPES[dtype],
+                                          _stream()))
+    return out, pos, counts
+
+
+def generateTransitionParallel(action, reward, state, next_state, terminal_state, grid_shift, trans_type=None,
+                               device=None):
+    """Drop-in for src/util_actor.py:223-264 on the GPU: same arguments, returns a numpy record
+    array of ``trans_type`` (default: transition_dtype(size), Actor_mp.py:52-56)."""
+    dev = _require_gpu(device)
+    L = _lib.load()
+    st = torch.as_tensor(np.ascontiguousarray(state)).to(device=dev, dtype=torch.uint8).contiguous()
+    nst = torch.as_tensor(np.ascontiguousarray(next_state)).to(device=dev, dtype=torch.uint8).contiguous()
+    act = torch.as_tensor(np.ascontiguousarray(action)).to(device=dev, dtype=torch.int32).contiguous()
+    n, d = int(nst.shape[0]), int(nst.shape[-1])
+    if int(grid_shift) != d // 2:
+        raise ValueError("grid_shift must be int(toric_size/2) (Actor_mp.py:59)")
+    out = dict(perspective=torch.empty((n, 2, d, d), dtype=torch.uint8, device=dev),
+               next_perspective=torch.empty((n, 2, d, d), dtype=torch.uint8, device=dev),
+               action=torch.empty((n, 4), dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        check(L.tq_states_transition(d, n, _ptr(st), _ptr(nst), _ptr(act), _ptr(out["perspective"]),
+                                     _ptr(out["next_perspective"]), _ptr(out["action"]), _stream()))
+    out["reward"] = np.asarray(reward, np.float64)
+    out["terminal"] = np.asarray(terminal_state, bool)
+    rec = to_structured(out, d)
+    return rec if trans_type is None else rec.astype(trans_type)

@@ -1,0 +1,73 @@
+"""Transition exchange between env shards: one process per GPU, RCCL gather over xGMI.
+
+The reference's actors push pickled lists of (transition, priority) through an mp.Queue to the
+replay process (Actor_mp.py:152-169, IO_mp.py:60-66; MPI variant: object gather,
+mpi/Actor_mpi.py:134-150).  Here every rank owns a contiguous block of env ids and contributes
+one fixed-size packed transition block per flush; rank 0 receives all of them into a replay
+ring that stays in its HBM (288 GB: ~7e9 transitions at d=7), so nothing crosses PCIe per step.
+Lattices never interact, so this gather is the ONLY collective of the path.
+
+Backend "nccl" is RCCL on ROCm (device buffers, xGMI point-to-point fan-in to the root);
+"gloo" (CPU tests, world_size 2) stages the same bytes through host tensors.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_envs, world_size, rank):
+    """Contiguous block of global env ids of `rank`: [first, first+count)."""
+    base, rem = divmod(int(total_envs), int(world_size))
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+class TransitionGather:
+    """Gathers equal-size byte blocks from every rank into a ring of `ring_slots` slots on rank 0.
+
+    ``gather(buf)`` enqueues the exchange of this flush's block (async on the collective's own
+    stream for nccl, so it overlaps the next env steps) and returns the ring slot it lands in;
+    ``wait()`` blocks until every outstanding exchange has completed.
+    """
+
+    def __init__(self, block_nbytes, device, ring_slots=2, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.nbytes = int(block_nbytes)
+        self.device = torch.device(device)
+        self.stage_device = self.device if self.backend == "nccl" else torch.device("cpu")
+        self.ring_slots = int(ring_slots)
+        self.ring = None
+        if self.rank == 0:
+            self.ring = torch.zeros((self.ring_slots, self.world, self.nbytes), dtype=torch.uint8,
+                                    device=self.stage_device)
+        self._next = 0
+        self._pending = []
+
+    def gather(self, buf):
+        if buf.dtype != torch.uint8 or buf.numel() != self.nbytes:
+            raise ValueError("block must be a uint8 tensor of block_nbytes elements")
+        slot = self._next % self.ring_slots
+        self._next += 1
+        src = buf if buf.device == self.stage_device else buf.to(self.stage_device)
+        outs = [self.ring[slot, r] for r in range(self.world)] if self.rank == 0 else None
+        work = dist.gather(src, gather_list=outs, dst=0, group=self.group, async_op=True)
+        self._pending.append((work, src))
+        if len(self._pending) >= self.ring_slots:          # never overwrite a slot still in flight
+            self._drain(1)
+        return slot
+
+    def _drain(self, keep):
+        while len(self._pending) > keep:
+            work, _ = self._pending.pop(0)
+            work.wait()
+
+    def wait(self):
+        self._drain(0)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def slot_view(self, slot, rank):
+        """Root only: the bytes rank `rank` contributed to ring slot `slot`."""
+        return self.ring[slot, rank]

@@ -182,6 +182,56 @@ def test_dense_syndrome_maximum_size(T):
     assert np.array_equal(cnt.cpu().numpy(), bcnt)
 
 
+@pytest.mark.parametrize("d", SIZES)
+@pytest.mark.parametrize("dtype", (torch.float32, torch.float16, torch.uint8))
+def test_line_ownership_with_empty_and_tiny_lattices(T, d, dtype):
+    """The write kernel assigns whole 128-byte lines to the lattice that owns the line's first
+    element; lines then hold elements of several lattices when these are empty or tiny.  Mix of
+    empty syndromes, single defect pairs and dense grids, every size and element width."""
+    rng = np.random.default_rng(1000 + d)
+    n = 777
+    st = np.zeros((n, 2, d, d), np.uint8)
+    kind = rng.integers(0, 4, n)
+    for e in range(n):
+        if kind[e] == 1:                                   # one defect pair (a handful of hits)
+            q = np.zeros((2, d, d), np.uint8)
+            q[rng.integers(0, 2), rng.integers(0, d), rng.integers(0, d)] = rng.integers(1, 4)
+            st[e] = O.syndrome(q)
+        elif kind[e] == 2:
+            st[e] = rng.random((2, d, d)) < 0.15
+        elif kind[e] == 3:
+            st[e] = rng.random((2, d, d)) < 0.7
+    st[:5] = 0                                             # a run of empty lattices at the start ...
+    st[-3:] = 0                                            # ... and at the end
+    per, pos, cnt = T.generatePerspectiveBatch(d // 2, d, st, dtype=dtype)
+    bp, bpos, bcnt, _ = O.generate_perspective_batch(st)
+    assert np.array_equal(cnt.cpu().numpy(), bcnt) and np.array_equal(pos.cpu().numpy(), bpos)
+    assert np.array_equal(per.float().cpu().numpy(), bp.astype(np.float32))
+    # exact-capacity buffer with a canary behind it: nothing may be written past the stack
+    P = int(bp.shape[0])
+    nq = 2 * d * d
+    env = T.make("toric-code-v0", {"size": d})
+    gpu = T.EnvSet(env, n, numpy_io=False)
+    q = np.zeros((n, 2, d, d), np.uint8)
+    gpu.setQubits(q)                                       # counts come from the handle: all empty
+    c0, off0 = gpu.perspectiveCounts()
+    assert int(off0[-1].item()) == 0
+    gpu.close()
+    flat = torch.full((P * nq + 256,), 7, dtype=dtype, device=per.device)
+    from toric_rl_decoder_amd import _lib
+    import ctypes as C
+    L = _lib.load()
+    dev_st = torch.as_tensor(st, device=per.device)
+    offs = torch.empty(n + 1, dtype=torch.int64, device=per.device)
+    _lib.check(L.tq_states_persp_count(d, n, C.c_void_p(dev_st.data_ptr()), None, C.c_void_p(offs.data_ptr()), None))
+    code = {torch.float32: 0, torch.float16: 1, torch.uint8: 3}[dtype]
+    _lib.check(L.tq_states_persp_write(d, n, C.c_void_p(dev_st.data_ptr()), C.c_void_p(offs.data_ptr()),
+                                       C.c_void_p(flat.data_ptr()), None, P, code, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(flat[:P * nq].float().cpu().numpy(), bp.astype(np.float32).reshape(-1))
+    assert bool((flat[P * nq:] == 7).all())
+
+
 def test_bad_actions_and_capacity_are_reported(T):
     d, n = 5, 100
     gpu, ora = make_pair(T, d, n)

@@ -405,44 +405,105 @@ __global__ __launch_bounds__(256) void k_block_unpack(BlockView b, int64_t first
 }
 
 // ------------------------------------------------------------------ exclusive scan of counts
-// One 1024-thread workgroup; each thread owns a contiguous chunk.  N = 65 536 -> 64 counts per
-// thread (256 KB read, 512 KB written): latency-, not bandwidth-bound, ~ a few microseconds.
-__global__ __launch_bounds__(1024) void k_scan(const int32_t* __restrict__ counts, int64_t* __restrict__ offsets,
-                                               int32_t* __restrict__ counts_out, int64_t N) {
-    __shared__ int64_t wave_tot[16];
+// Two-level scan, SCAN_CHUNK = 2048 counts per 256-thread workgroup (8 per thread, two int4
+// loads): k_scan_partials writes one sum per chunk; k_scan_final re-reads its chunk, adds the sums
+// of the chunks before it (<= N/2048 values, one strided wave reduction) and writes offsets.
+constexpr int SCAN_CHUNK = 2048;
+
+__device__ __forceinline__ int64_t wave_sum64(int64_t x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+__device__ __forceinline__ void scan_load8(const int32_t* __restrict__ counts, int64_t N, int64_t i0, int (&c)[8]) {
+    if (i0 + 8 <= N) {
+        const int4 a = *reinterpret_cast<const int4*>(counts + i0);
+        const int4 b = *reinterpret_cast<const int4*>(counts + i0 + 4);
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = i0 + k < N ? counts[i0 + k] : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_partials(const int32_t* __restrict__ counts, int64_t* __restrict__ partial,
+                                                       int64_t N) {
+    __shared__ int64_t ws[4];
+    int c[8];
+    scan_load8(counts, N, (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * 8, c);
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += c[k];
+    s = wave_sum64(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_final(const int32_t* __restrict__ counts, const int64_t* __restrict__ partial,
+                                                    int64_t* __restrict__ offsets, int32_t* __restrict__ counts_out,
+                                                    int64_t N) {
+    __shared__ int64_t ws[4];
+    __shared__ int64_t base_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t chunk = (N + 1023) / 1024;
-    const int64_t lo = (int64_t)tid * chunk;
-    const int64_t hi = lo + chunk < N ? lo + chunk : N;
-    int64_t sum = 0;
-    for (int64_t i = lo; i < hi; ++i) sum += counts[i];
-    int64_t inc = sum;                                       // inclusive scan across the wave
+    const int64_t i0 = (int64_t)blockIdx.x * SCAN_CHUNK + tid * 8;
+    int c[8];
+    scan_load8(counts, N, i0, c);
+    int64_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mine += c[k];
+    int64_t inc = mine;                                       // inclusive scan of thread sums in the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int64_t t = __shfl_up(inc, o, 64);
         if (lane >= o) inc += t;
     }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    int64_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wave_tot[w];
-    int64_t run = base + inc - sum;
-    for (int64_t i = lo; i < hi; ++i) {
-        const int32_t c = counts[i];
-        offsets[i] = run;
-        if (counts_out) counts_out[i] = c;
-        run += c;
+    if (lane == 63) ws[wave] = inc;
+    if (wave == 0) {                                          // sum of the chunks before this one
+        int64_t b = 0;
+        for (int j = lane; j < (int)blockIdx.x; j += 64) b += partial[j];
+        b = wave_sum64(b);
+        if (lane == 0) base_s = b;
     }
-    if (tid == 1023) offsets[N] = base + inc;
+    __syncthreads();
+    int64_t run = base_s + inc - mine;
+    for (int w = 0; w < wave; ++w) run += ws[w];
+    if (i0 + 8 <= N) {
+        int64_t o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { o[k] = run; run += c[k]; }
+        longlong2* dst = reinterpret_cast<longlong2*>(offsets + i0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = make_longlong2(o[2 * k], o[2 * k + 1]);
+        if (counts_out) {
+            *reinterpret_cast<int4*>(counts_out + i0) = make_int4(c[0], c[1], c[2], c[3]);
+            *reinterpret_cast<int4*>(counts_out + i0 + 4) = make_int4(c[4], c[5], c[6], c[7]);
+        }
+        if (i0 + 8 == N) offsets[N] = run;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < N) {
+                offsets[i0 + k] = run;
+                if (counts_out) counts_out[i0 + k] = c[k];
+                run += c[k];
+                if (i0 + k + 1 == N) offsets[N] = run;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ perspective stack write
-template <typename T> struct OutVal;
-template <> struct OutVal<float> { static __device__ __forceinline__ float of(unsigned b) { return (float)b; } };
-template <> struct OutVal<__half> { static __device__ __forceinline__ __half of(unsigned b) { return __ushort_as_half((unsigned short)(b ? 0x3C00 : 0)); } };
+// Element encodings of the stack: how the bit b in {0,1} of a syndrome cell is stored, and how the
+// elements of one 16-byte lane store are packed into four dwords.
 struct bf16_t { unsigned short u; };
-template <> struct OutVal<bf16_t> { static __device__ __forceinline__ bf16_t of(unsigned b) { return bf16_t{(unsigned short)(b ? 0x3F80 : 0)}; } };
-template <> struct OutVal<uint8_t> { static __device__ __forceinline__ uint8_t of(unsigned b) { return (uint8_t)b; } };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct OutEnc;
+template <> struct OutEnc<float> { static constexpr int BITS = 32; static constexpr uint32_t ONE = 0x3F800000u; };
+template <> struct OutEnc<__half> { static constexpr int BITS = 16; static constexpr uint32_t ONE = 0x3C00u; };
+template <> struct OutEnc<bf16_t> { static constexpr int BITS = 16; static constexpr uint32_t ONE = 0x3F80u; };
+template <> struct OutEnc<uint8_t> { static constexpr int BITS = 8; static constexpr uint32_t ONE = 1u; };
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS ops of one wave execute in order; this only stops the compiler from moving LDS
@@ -464,84 +525,179 @@ __global__ void k_build_lut(uint8_t* __restrict__ lut) {
 }
 
 // vp = V/P planes: V word k of lattice e at vp[(0*W+k)*N+e], P at vp[(1*W+k)*N+e].
+//
+// One wavefront per lattice (the hardware dispatcher balances the variable-size lattices).
+// Ownership rule for the output: the stack is cut into 128-byte lines of the address space and a
+// line is written -- whole -- by the wave of the lattice that contains the line's FIRST element.
+// Two waves (usually on different XCDs, whose L2s are not coherent) therefore never write parts
+// of one line; measured +6.5 % over byte-exact segment ownership (tools/membench3.hip).
+//   * lines entirely inside the lattice's segment: the fast loop, one 16-byte store per lane,
+//     1 KiB = 8 whole lines per wave instruction, (perspective, cell) carried incrementally;
+//   * the last owned line, when the segment ends inside it: lanes 0..31 store one dword each; its
+//     trailing elements belong to the following lattice(s) and are resolved from their bit-planes.
+// The leading elements of a segment that sit in a line begun by an earlier lattice are written by
+// that lattice's wave, by the same rule.
 template <int D, typename OutT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restrict__ vp, int64_t N,
                                                          const int64_t* __restrict__ offsets, OutT* __restrict__ out,
                                                          int32_t* __restrict__ pos, int64_t capacity,
                                                          const uint8_t* __restrict__ lut_g, int* __restrict__ err) {
     using L = Lat<D>;
+    using Enc = OutEnc<OutT>;
     constexpr int DD = L::DD, NQ = L::NQ, W = L::W;
     constexpr int WAVES = THREADS / 64;
     constexpr int VEC = 16 / (int)sizeof(OutT);              // elements per 16-byte lane store
+    constexpr int EPW = 32 / Enc::BITS;                      // elements per dword
+    constexpr int LE = 128 / (int)sizeof(OutT);              // elements per 128-byte line
     constexpr int LUT_BYTES = (NQ * NQ + 15) & ~15;
     constexpr int NQP = (NQ + 3) & ~3;
     __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
     __shared__ uint8_t cellv[WAVES][NQP];                    // syndrome cells (0/1) of the wave's lattice
-    __shared__ uint8_t hits[WAVES][NQP];                     // k-th hit -> flat qubit index
-
-    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
-        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
-    __syncthreads();
+    __shared__ uint16_t hits[WAVES][NQP];                    // k-th hit -> flat qubit index * NQ (its LUT row offset)
 
     // the wave index is made provably uniform so that the lattice id, its plane words and its
     // offset live in SGPRs (scalar loads) and the hit masks are computed on the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * WAVES;
-    for (int64_t e = (int64_t)blockIdx.x * WAVES + wave; e < N; e += stride) {
-        typename L::B v, p, e0, e1;
+    const int64_t e = (int64_t)blockIdx.x * WAVES + wave;
+    const bool live = e < N;
+    typename L::B v, p, e0, e1;
+    int n0 = 0, n = 0;
+    int64_t off = 0;
+    if (live) {
 #pragma unroll
         for (int k = 0; k < W; ++k) { v.w[k] = vp[(int64_t)k * N + e]; p.w[k] = vp[((int64_t)W + k) * N + e]; }
         L::hit_masks(v, p, e0, e1);
-        const int n0 = e0.popc();
-        const int n = n0 + e1.popc();
-        const int64_t off = offsets[e];
-        if (off + n > capacity) { if (lane == 0) atomicOr(err, ERR_CAPACITY); continue; }
-
+        n0 = e0.popc();
+        n = n0 + e1.popc();
+        off = offsets[e];
+    }
+    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
+        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
+    if (live && n > 0) {
         for (int c = lane; c < NQ; c += 64) {
             const int l = c >= DD, bit = c - l * DD;
             cellv[wave][c] = (uint8_t)(l ? p.get(bit) : v.get(bit));
             const int is_hit = l ? e1.get(bit) : e0.get(bit);
-            if (is_hit) hits[wave][l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint8_t)c;
+            if (is_hit) hits[wave][l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint16_t)(c * NQ);
         }
-        wave_lds_sync();
+    }
+    __syncthreads();
+    if (!live || n == 0) return;
+    if (off + n > capacity) { if (lane == 0) atomicOr(err, ERR_CAPACITY); return; }
+    const uint16_t* __restrict__ hw = hits[wave];
+    const uint8_t* __restrict__ cw = cellv[wave];
 
-        if (pos) {                                           // positions (P,3): (layer,row,col) of each hit
-            for (int k = lane; k < 3 * n; k += 64) {
-                const int hidx = k / 3, comp = k - 3 * hidx;
-                const int h = hits[wave][hidx];
-                const int l = h >= DD, rem = h - l * DD, row = rem / D, col = rem - row * D;
-                pos[off * 3 + k] = comp == 0 ? l : (comp == 1 ? row : col);
-            }
+    if (pos) {                                               // positions (P,3): (layer,row,col) of each hit
+        for (int k = lane; k < 3 * n; k += 64) {
+            const int hidx = k / 3, comp = k - 3 * hidx;
+            const int h = hw[hidx] / NQ;
+            const int l = h >= DD, rem = h - l * DD, row = rem / D, col = rem - row * D;
+            pos[off * 3 + k] = comp == 0 ? l : (comp == 1 ? row : col);
         }
+    }
 
-        // the lattice's contiguous output segment [lo, hi) in elements, cut into 16-byte groups
-        const int total = n * NQ;
-        const int64_t lo = off * NQ;
-        const int64_t g_first = lo / VEC;
-        const int64_t g_last = (lo + total + VEC - 1) / VEC;
-        for (int64_t g = g_first + lane; g < g_last; g += 64) {
-            const int rel0 = (int)(g * VEC - lo);           // even; < 0 only for the first group
-            OutT vals[VEC];
+    const int total = n * NQ;
+    const int64_t lo = off * NQ, hi = lo + total;            // the lattice's segment, in elements
+    const int64_t A = (lo + LE - 1) / LE * LE;               // first line start >= lo
+    const int64_t F = hi / LE * LE;                          // last line start <= hi
+
+    // ---- whole lines inside the segment: [A, F)
+    if (F > A) {
+        // Lane `lane` writes 16-byte groups lane, lane+64, ... of [A, F); its first element sits
+        // `rel` elements into the segment = perspective `pidx`, cell `cell`.  One iteration advances
+        // by 64*VEC elements = DP perspectives + DC cells: no division in the loop, 32-bit offsets
+        // from a wave-uniform base.
+        constexpr int STEP = 64 * VEC, DP = STEP / NQ, DC = STEP % NQ;
+        const int n_groups = (int)((F - A) / VEC);
+        char* __restrict__ seg = reinterpret_cast<char*>(out + A);            // wave-uniform, 128-byte aligned
+        int pidx, cell;
+        {
+            const int rel = (int)(A - lo) + lane * VEC;
+            pidx = rel / NQ;
+            cell = rel - pidx * NQ;
+        }
+        for (int gi = lane; gi < n_groups; gi += 64) {
+            uint32_t wd[4] = {0u, 0u, 0u, 0u};
+            int pp = pidx, cc = cell;
 #pragma unroll
-            for (int k = 0; k < VEC; k += 2) {              // NQ and rel0 are even: a pair never straddles two perspectives
-                int rel = rel0 + k;
-                rel = rel < 0 ? 0 : (rel > total - 2 ? total - 2 : rel);
+            for (int k = 0; k < VEC; k += 2) {              // NQ and cell are even: a pair never straddles two perspectives
+                const unsigned src2 = *reinterpret_cast<const unsigned short*>(&lut[hw[pp] + cc]);
+                const uint32_t b0 = cw[src2 & 255], b1 = cw[src2 >> 8];
+                if (Enc::BITS == 32) {
+                    wd[k] = __float_as_uint((float)b0);      // v_cvt_f32_ubyte0
+                    wd[k + 1] = __float_as_uint((float)b1);
+                } else {
+                    wd[k / EPW] |= ((0u - b0) & Enc::ONE) << ((k % EPW) * Enc::BITS);
+                    wd[(k + 1) / EPW] |= ((0u - b1) & Enc::ONE) << (((k + 1) % EPW) * Enc::BITS);
+                }
+                if (k + 2 < VEC) {
+                    cc += 2;
+                    const bool wrap = cc >= NQ;
+                    cc = wrap ? cc - NQ : cc;
+                    pp = wrap ? pp + 1 : pp;
+                }
+            }
+            const u32x4 v4 = {wd[0], wd[1], wd[2], wd[3]};
+            *reinterpret_cast<u32x4*>(seg + (uint32_t)gi * 16u) = v4;
+            cell += DC;
+            pidx += DP;
+            const bool wrap = cell >= NQ;
+            cell = wrap ? cell - NQ : cell;
+            pidx = wrap ? pidx + 1 : pidx;
+        }
+    }
+
+    // ---- the line [F, F+LE) when the segment ends inside it (F >= lo: its start is ours)
+    if (F >= lo && F < hi && lane < 32) {
+        const int64_t total_end = offsets[N] * NQ;
+        const int64_t cap_end = capacity * NQ;
+        const int64_t limit = total_end < cap_end ? total_end : cap_end;      // nothing is written at or beyond it
+        const int64_t line_end = F + LE;
+        const int64_t x0 = F + lane * EPW;                   // this lane's dword = elements x0 .. x0+EPW-1
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < EPW; ++j) {                      // own elements
+            const int64_t x = x0 + j;
+            if (x < hi) {
+                const int rel = (int)(x - lo);
                 const int pidx = rel / NQ, cell = rel - pidx * NQ;
-                const int h = hits[wave][pidx];
-                const unsigned src2 = *reinterpret_cast<const unsigned short*>(&lut[h * NQ + cell]);
-                vals[k] = OutVal<OutT>::of(cellv[wave][src2 & 255]);
-                vals[k + 1] = OutVal<OutT>::of(cellv[wave][src2 >> 8]);
-            }
-            OutT* dst = out + g * VEC;
-            if (rel0 >= 0 && rel0 + VEC <= total) {
-                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(vals);
-            } else {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k)
-                    if (rel0 + k >= 0 && rel0 + k < total) dst[k] = vals[k];
+                const uint32_t b = cw[lut[hw[pidx] + cell]];
+                word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
             }
         }
-        wave_lds_sync();
+        // elements of the lattices that follow, up to the end of the line (wave-uniform walk)
+        int64_t e2 = e + 1, pos2 = hi;
+        while (e2 < N && pos2 < line_end && pos2 < limit) {
+            typename L::B v2, p2, f0, f1;
+#pragma unroll
+            for (int k = 0; k < W; ++k) { v2.w[k] = vp[(int64_t)k * N + e2]; p2.w[k] = vp[((int64_t)W + k) * N + e2]; }
+            L::hit_masks(v2, p2, f0, f1);
+            const int n2 = f0.popc() + f1.popc();
+            const int64_t end2 = pos2 + (int64_t)n2 * NQ;
+#pragma unroll
+            for (int j = 0; j < EPW; ++j) {
+                const int64_t x = x0 + j;
+                if (x >= pos2 && x < end2) {
+                    const int rel = (int)(x - pos2);         // < LE
+                    const int pidx = rel / NQ, cell = rel - pidx * NQ;
+                    const int src = lut[kth_hit<D>(f0, f1, pidx) * NQ + cell];
+                    const uint32_t b = (uint32_t)(src >= DD ? p2.get(src - DD) : v2.get(src));
+                    word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
+                }
+            }
+            pos2 = end2;
+            ++e2;
+        }
+        if (x0 + EPW <= limit) {
+            reinterpret_cast<uint32_t*>(out)[x0 / EPW] = word;
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPW; ++j)                    // the stack ends inside this dword
+                if (x0 + j < limit) {
+                    if (Enc::BITS == 16) reinterpret_cast<uint16_t*>(out)[x0 + j] = (uint16_t)(word >> (16 * j));
+                    else if (Enc::BITS == 8) reinterpret_cast<uint8_t*>(out)[x0 + j] = (uint8_t)(word >> (8 * j));
+                }
+        }
     }
 }
 

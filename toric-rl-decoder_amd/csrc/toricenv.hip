@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -97,14 +98,23 @@ int get_lut(int dev, int d, hipStream_t stream, const uint8_t** out) {
     return TQ_OK;
 }
 
+int launch_scan(const int32_t* counts, int64_t* partial, int64_t* offsets, int32_t* counts_out, int64_t n,
+                hipStream_t stream) {
+    const unsigned blocks = (unsigned)((n + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK);
+    hipLaunchKernelGGL(tq::k_scan_partials, dim3(blocks), dim3(256), 0, stream, counts, partial, n);
+    hipLaunchKernelGGL(tq::k_scan_final, dim3(blocks), dim3(256), 0, stream, counts, (const int64_t*)partial, offsets,
+                       counts_out, n);
+    KCHECK();
+    return TQ_OK;
+}
+
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, const uint8_t* lut, int* err, int num_cus, hipStream_t stream) {
     constexpr int THREADS = D <= 7 ? 256 : (D == 9 ? 512 : 1024);
     constexpr int WAVES = THREADS / 64;
-    const int64_t want = (n + WAVES - 1) / WAVES;
-    const int64_t resident = (int64_t)num_cus * (2048 / THREADS);   // 32 waves per CU
-    const int64_t blocks = want < resident ? want : resident;
+    // one lattice per wave: the hardware dispatcher balances the variable-size lattices
+    const int64_t blocks = (n + WAVES - 1) / WAVES;
     hipLaunchKernelGGL((tq::k_persp_write<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
                        offsets, (OutT*)out, pos, capacity, lut, err);
     KCHECK();
@@ -137,6 +147,7 @@ struct tq_env {
     uint32_t* episodes;
     uint32_t* steps;
     int32_t* counts;
+    int64_t* partial;      // scan scratch: one sum per 2048 counts
     double* p_roof;
     int* err;              // device error latch
     const uint8_t* lut;
@@ -187,7 +198,8 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc((void**)&h->prev, 2 * W * N * 8);
     alloc((void**)&h->episodes, N * 4);
     alloc((void**)&h->steps, N * 4);
-    alloc((void**)&h->counts, N * 4);
+    alloc((void**)&h->counts, N * 4 + 32);                      // +32: int4 tail loads of the scan stay in bounds
+    alloc((void**)&h->partial, ((N + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK) * 8);
     alloc((void**)&h->p_roof, N * 8);
     alloc((void**)&h->err, 4);
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
@@ -201,7 +213,7 @@ int tq_destroy(tq_env* h) {
     if (!h) return TQ_OK;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->planes); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
-    (void)hipFree(h->counts); (void)hipFree(h->p_roof); (void)hipFree(h->err);
+    (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->err);
     delete h;
     return TQ_OK;
 }
@@ -342,8 +354,7 @@ int tq_is_terminal(tq_env* h, uint8_t* out, void* stream_) {
 int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream_) {
     HANDLE(h);
     if (!offsets) return fail(TQ_E_INVALID, "offsets is NULL");
-    hipLaunchKernelGGL(tq::k_scan, dim3(1), dim3(1024), 0, stream, h->counts, offsets, counts, (int64_t)h->n);
-    KCHECK();
+    if (int rc = launch_scan(h->counts, h->partial, offsets, counts, h->n, stream)) return rc;
     return TQ_OK;
 }
 
@@ -360,11 +371,13 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
 }
 
 // ---- stateless variants (states outside a handle) -------------------------------------------
-static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int** err) {
+static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int** err) {
     DeviceCtx& c = g_ctx[dev];
     std::lock_guard<std::mutex> lock(c.mu);
     const size_t w = (size_t)(d * d + 63) / 64;
-    const size_t need = 2 * w * (size_t)n * 8 + (((size_t)n * 4 + 15) & ~(size_t)15) + 16;
+    const size_t cnt_bytes = (((size_t)n * 4 + 32 + 15) & ~(size_t)15);
+    const size_t part_bytes = (((size_t)n + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK) * 8;
+    const size_t need = 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes + 16;
     if (c.ws_bytes < need) {
         if (c.ws) HIPCHECK(hipFree(c.ws));
         c.ws = nullptr; c.ws_bytes = 0;
@@ -374,6 +387,7 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
     }
     *vp = (uint64_t*)c.ws;
     *counts = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8);
+    *partial = (int64_t*)((char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes);
     *err = (int*)((char*)c.ws + need - 16);
     return TQ_OK;
 }
@@ -384,14 +398,13 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
     if (n <= 0 || !states || !offsets) return fail(TQ_E_INVALID, "bad n / states / offsets");
     int dev;
     if (int rc = current_device(&dev)) return rc;
-    uint64_t* vp; int32_t* cnt; int* err;
-    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &err)) return rc;
+    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
 #define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, cnt, (int64_t)n)
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-    hipLaunchKernelGGL(tq::k_scan, dim3(1), dim3(1024), 0, stream, cnt, offsets, counts, (int64_t)n);
-    KCHECK();
+    if (int rc = launch_scan(cnt, part, offsets, counts, n, stream)) return rc;
     return TQ_OK;
 }
 
@@ -404,8 +417,8 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut;
     if (int rc = get_lut(dev, d, stream, &lut)) return rc;
-    uint64_t* vp; int32_t* cnt; int* err;
-    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &err)) return rc;
+    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
 #define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, (int32_t*)nullptr, (int64_t)n)
     DISPATCH_D(d, CALL)
 #undef CALL
@@ -425,8 +438,8 @@ int tq_states_transition(int d, int n, const uint8_t* states, const uint8_t* nex
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut;
     if (int rc = get_lut(dev, d, stream, &lut)) return rc;
-    uint64_t* vp; int32_t* cnt; int* err;
-    if (int rc = states_scratch(dev, d, 1, &vp, &cnt, &err)) return rc;
+    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
+    if (int rc = states_scratch(dev, d, 1, &vp, &cnt, &part, &err)) return rc;
     const int64_t total = (int64_t)n * 2 * d * d;
 #define CALL(D) hipLaunchKernelGGL(tq::k_states_transition<D>, grid1(total, 256), dim3(256), 0, stream, states, next_states, \
         actions, persp, next_persp, actions_out, lut, (int64_t)n, err)

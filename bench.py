@@ -60,13 +60,16 @@ def cpu_baseline(d, p, seed, budget_s):
     restated, oracle/toric_oracle.c) timed on the host cores: bounded sample of the same workload."""
     from oracle.c_oracle import CEnvBatch, lib
     L = lib()
-    threads = L.tor_num_threads()
+    # host cores this process may use (the GPU box gives one GPU's share of a big host)
+    threads = max(1, min(len(os.sched_getaffinity(0)), L.tor_num_threads(), int(os.environ.get("TORIC_CPU_THREADS", "16"))))
+    L.tor_set_threads(threads)
     n = 4096
     env = CEnvBatch(d, n, p, seed=seed)
     env.reset()
+    env.actor_steps(2)                                        # page in, spin up the thread team
     t0 = time.perf_counter()
-    env.actor_steps(2)
-    probe = (time.perf_counter() - t0) / 2
+    env.actor_steps(8)
+    probe = (time.perf_counter() - t0) / 8
     steps = int(max(4, min(2000, budget_s / max(probe, 1e-6))))
     t0 = time.perf_counter()
     P, _ = env.actor_steps(steps)

@@ -124,6 +124,12 @@ int tq_select_action(tq_env* h, const float* q_table, const int64_t* offsets,
                      const int32_t* positions, const double* eps, int32_t* actions,
                      float* q_values, void* stream);
 
+/* predictMaxOptimized's reduction (util_learner.py:96-110): out[i] = max over the (n_i,3) slice of
+ * q_table, 0 for states without perspectives; `largest` = device i32[1] holding the longest slice
+ * length reproduces the reference's zero padding (shorter slices get max(max_q, 0)); NULL = plain max. */
+int tq_segment_max(const float* q_table, const int64_t* offsets, int n, const int32_t* largest,
+                   float* out, void* stream);
+
 /* generateTransitionParallel (util_actor.py:223-264) for the last tq_step: perspective of the
  * pre-step and post-step syndrome centred on the acted qubit (rotated for layer 1), action
  * rewritten to (layer, gs, gs, op).  Outputs (any may be NULL): persp u8[N,2,d,d],

@@ -1,0 +1,114 @@
+"""Policy-side callers of the hot path on the GPU against oracle loops.
+The Q-network is replaced by an integer-weight linear map: exact in fp32 on CPU and GPU, with many
+ties, so the first-maximum rule is exercised and results are bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import toric_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import toric_rl_decoder_amd as T
+    assert torch.cuda.is_available()
+    T.load()
+    return T
+
+
+class IntQ(torch.nn.Module):
+    def __init__(self, d, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w = torch.nn.Parameter(torch.randint(-2, 3, (2 * d * d, 3), generator=g).float(), requires_grad=False)
+
+    def forward(self, x):
+        return x.flatten(1).float() @ self.w
+
+
+def oracle_q(model, persp):
+    return (persp.reshape(persp.shape[0], -1).astype(np.float32) @ model.w.cpu().numpy()).astype(np.float32)
+
+
+@pytest.mark.parametrize("d", (3, 5, 7))
+def test_select_action_batch_with_model(T, d):
+    n = 600
+    env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+    gpu = T.EnvSet(env, n, seed=8, numpy_io=True)
+    ora = O.OracleEnvSet(d, n, 0.1, seed=8)
+    model = IntQ(d).to(gpu.device)
+    assert np.array_equal(gpu.resetAll(), ora.resetAll())
+    rng = np.random.default_rng(d)
+    for t in range(10):
+        eps = rng.random(n) * 0.6
+        act, qv = T.selectActionBatch(gpu, model, eps)
+        bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+        oact, oqv, _ = O.select_action_batch(oracle_q(model, bp), boff, bpos, eps, ora.seed, ora.env_ids,
+                                             ora.episodes, ora.steps)
+        assert np.array_equal(act, oact) and np.array_equal(qv, oqv)
+        ns, r, term, _ = gpu.step(act)                      # solved lattices carry op 0: no-op, no error
+        ons, orr, oterm, _ = ora.step(oact)
+        assert np.array_equal(ns, ons) and np.array_equal(r, orr) and np.array_equal(term, oterm)
+    assert (act[term][:, 3] == 0).sum() >= 0
+    gpu.close()
+
+
+@pytest.mark.parametrize("d", (5, 7, 9))
+def test_predict_max_optimized(T, d):
+    """util_learner.py:48-111 incl. the zero-padding quirk and terminal states."""
+    rng = np.random.default_rng(50 + d)
+    n = 300
+    _, st = O.reset_lattices(5, np.arange(n), 0, 0.08, d)
+    st[::7] = 0                                              # terminal states in the batch
+    model = IntQ(d, seed=3).cuda()
+    got = T.predictMaxOptimized(model, st, d // 2, d, "cuda").cpu().numpy()
+    bp, _, cnt, off = O.generate_perspective_batch(st)
+    q = oracle_q(model, bp)
+    largest = max(1, int(cnt.max()))
+    want = np.zeros(n, np.float32)
+    for i in range(n):
+        if cnt[i] == 0:
+            continue
+        m = q[off[i]:off[i + 1]].max()
+        want[i] = max(m, 0.0) if cnt[i] < largest else m     # reference pads shorter slices with zero rows
+    assert np.array_equal(got, want)
+    # plain segmented maximum (no padding)
+    qd = torch.as_tensor(q, device="cuda")
+    plain = T.segment_max(qd, torch.as_tensor(off, device="cuda")).cpu().numpy()
+    ref = np.array([q[off[i]:off[i + 1]].max() if cnt[i] else 0.0 for i in range(n)], np.float32)
+    assert np.array_equal(plain, ref)
+
+
+def test_evaluate_matches_oracle_loop(T):
+    """evaluation.py:10-124, episodes batched; compared with the same loop on the oracle."""
+    d, episodes, max_steps = 5, 400, 12
+    model = IntQ(d, seed=1)
+    ps = [0.05, 0.12]
+    corrected, ground, steps_avg, mean_q, failed = T.evaluate(model, "toric-code-v0", {"size": d, "min_qubit_errors": 0},
+                                                             d // 2, "cuda", ps, num_of_episodes=episodes,
+                                                             num_of_steps=max_steps, seed=21)
+    for i, p in enumerate(ps):
+        env = O.OracleEnvSet(d, episodes, p, seed=21 + i)
+        env.resetAll()
+        done = np.zeros(episodes, bool)
+        steps = np.zeros(episodes, np.int64)
+        qs, qn = 0.0, 0
+        for _ in range(max_steps):
+            bp, bpos, bcnt, boff = O.generate_perspective_batch(env.states)
+            act, qv, _ = O.select_action_batch(oracle_q(model, bp), boff, bpos, 0.0, env.seed, env.env_ids,
+                                               env.episodes, env.steps)
+            live = ~done
+            chosen = qv[np.arange(episodes), np.clip(act[:, 3] - 1, 0, 2)]
+            qs += float((chosen.astype(np.float64) * live).sum())
+            qn += int(live.sum())
+            steps += live
+            _, _, term, _ = env.step(act)
+            done |= term
+            if done.all():
+                break
+        gs = O.eval_ground_state(env.qubits)
+        assert np.isclose(corrected[i], done.mean(), atol=1e-12) and np.isclose(ground[i], gs.mean(), atol=1e-12)
+        assert steps_avg[i] == np.round(steps.mean(), 1) and mean_q[i] == np.round(qs / max(qn, 1), 3)
+    assert len(failed) % 2 == 0

@@ -9,5 +9,7 @@ from ._lib import ToricEnvError, build, load, LIB_PATH  # noqa: F401
 from .envset import (EnvSet, ToricEnv, TransitionBlock, generatePerspectiveBatch,  # noqa: F401
                      generateTransitionParallel, make, to_structured, transition_dtype, SUPPORTED_SIZES)
 
-__all__ = ["EnvSet", "ToricEnv", "TransitionBlock", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
+from .policy import NN_11, evaluate, predictMaxOptimized, segment_max, selectActionBatch  # noqa: F401,E402
+
+__all__ = ["NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "EnvSet", "ToricEnv", "TransitionBlock", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
            "transition_dtype", "ToricEnvError", "build", "load", "LIB_PATH", "SUPPORTED_SIZES"]

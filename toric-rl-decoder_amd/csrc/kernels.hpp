@@ -121,6 +121,9 @@ __device__ __forceinline__ bool action_ok(int layer, int row, int col, int op) {
     return ((unsigned)layer < 2u) & ((unsigned)row < (unsigned)D) & ((unsigned)col < (unsigned)D) &
            ((unsigned)(op - 1) < 3u);
 }
+// op == 0 is "no action" (what tq_select_action emits for a lattice without defects): the step is
+// counted, nothing changes, and no error is latched.
+__device__ __forceinline__ bool action_noop(int op) { return op == 0; }
 
 // ------------------------------------------------------------------ step (EnvSet.step)
 template <int D>
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void k_step(uint64_t* __restrict__ planes, uin
     store_plane<W>(prev, 1, N, e, s.p);
     const int before = s.v.popc() + s.p.popc();
     if (action_ok<D>(a.x, a.y, a.z, a.w)) L::apply(s, a.x, a.y, a.z, a.w);
-    else atomicOr(err, ERR_ACTION);
+    else if (!action_noop(a.w)) atomicOr(err, ERR_ACTION);
     L::syndrome(s);
     const int after = s.v.popc() + s.p.popc();
     store_state<D>(planes, N, e, s);
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
         const int4 a = reinterpret_cast<const int4*>(actions)[e];
         layer = a.x; row = a.y; col = a.z; op = a.w;
         ok = action_ok<D>(layer, row, col, op);
-        if (!ok) atomicOr(err, ERR_ACTION);
+        if (!ok && !action_noop(op)) atomicOr(err, ERR_ACTION);
     } else {
         // non-greedy branch of _selectActionBatch_prime (numba/util_actor.py:97-98)
         typename L::B e0, e1;
@@ -766,6 +769,26 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ q, con
         if (qv) qv[3 * e + lane] = q ? q[3 * (lo + pidx) + lane] : 0.f;
     }
     if (lane == 3) actions[4 * e + 3] = a + 1;
+}
+
+// The learner's target max (util_learner.py:48-111, predictMaxOptimized): per state the maximum of
+// its (n_i, 3) Q-slice.  The reference pads every slice with zero rows up to the longest one before
+// the argmax (:98-100), so a state with fewer perspectives than the longest gets max(max_q, 0);
+// states without perspectives (terminal) give 0 (:74-76,108).  One wavefront per state.
+__global__ __launch_bounds__(256) void k_segment_max(const float* __restrict__ q, const int64_t* __restrict__ offsets,
+                                                     const int32_t* __restrict__ largest, float* __restrict__ out, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (e >= n) return;
+    const int64_t lo = offsets[e];
+    const int cnt = (int)(offsets[e + 1] - lo);
+    float best = -__builtin_inff();
+    for (int k = lane; k < 3 * cnt; k += 64) best = fmaxf(best, q[3 * lo + k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (cnt == 0) best = 0.f;
+    else if (largest && cnt < *largest) best = fmaxf(best, 0.f);
+    if (lane == 0) out[e] = best;
 }
 
 }  // namespace tq

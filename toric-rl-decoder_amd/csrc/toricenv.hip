@@ -462,6 +462,16 @@ int tq_select_action(tq_env* h, const float* q_table, const int64_t* offsets, co
     return TQ_OK;
 }
 
+int tq_segment_max(const float* q_table, const int64_t* offsets, int n, const int32_t* largest, float* out,
+                   void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0 || !offsets || !out) return fail(TQ_E_INVALID, "bad n / offsets / out");
+    hipLaunchKernelGGL(tq::k_segment_max, grid1((int64_t)n * 64, 256), dim3(256), 0, stream, q_table, offsets, largest,
+                       out, (int64_t)n);
+    KCHECK();
+    return TQ_OK;
+}
+
 int64_t tq_transition_block_bytes(int d, int64_t cap) {
     if (!size_ok(d) || cap < 0) return -1;
     return tq::block_bytes((d * d + 63) / 64, cap);

@@ -1,0 +1,145 @@
+"""Policy-side glue around the env kernels (callers of the hot path).
+
+The Q-network itself is stock torch convolution work and out of scope; NN_11 is restated here
+(30 lines, same parameter names as the reference so its state_dicts load unchanged) only so that
+BASELINE configs[2] ("generatePerspective feeding NN_11 policy for selectAction") and the
+evaluation loop can run without the reference's Python.
+
+  selectActionBatch    src/numba/util_actor.py:11-53
+  predictMaxOptimized  src/util_learner.py:48-111
+  evaluate             src/evaluation.py:10-124
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check
+from .envset import EnvSet, ToricEnv, _ptr, _stream, generatePerspectiveBatch
+
+
+class NN_11(nn.Module):
+    """11 conv3x3 + ReLU then one linear layer (src/nn/torch/NN.py:10-45); the first and the last
+    convolution are unpadded after a circular pad of 1 (src/nn/torch/util.py:21-26)."""
+
+    CHANNELS = (2, 128, 128, 120, 111, 104, 103, 90, 80, 73, 71, 64)
+
+    def __init__(self, system_size, number_of_actions=3, device=None):
+        super().__init__()
+        ch = self.CHANNELS
+        for i in range(11):
+            pad = 0 if i in (0, 10) else 1
+            setattr(self, f"conv{i + 1}", nn.Conv2d(ch[i], ch[i + 1], kernel_size=3, stride=1, padding=pad))
+        self.linear1 = nn.Linear(64 * (system_size - 2) ** 2, number_of_actions)
+        self.device = device
+
+    def forward(self, x):
+        x = F.pad(x, (1, 1, 1, 1), mode="circular")
+        for i in range(11):
+            x = F.relu(getattr(self, f"conv{i + 1}")(x))
+        return self.linear1(x.flatten(1))
+
+
+def _forward_chunked(model, persp, chunk):
+    outs = []
+    with torch.no_grad():
+        for i in range(0, persp.shape[0], chunk):
+            outs.append(model(persp[i:i + chunk]).float())
+    if not outs:
+        return torch.zeros((0, 3), dtype=torch.float32, device=persp.device)
+    return torch.cat(outs, dim=0)
+
+
+def selectActionBatch(envs, model, epsilon, dtype=torch.float32, chunk=1 << 16):
+    """selectActionBatch(number_of_actions, epsilon, grid_shift, toric_size, state, model, device)
+    of the reference for the lattices of ``envs`` (an EnvSet), everything on the device:
+    perspectives -> model forward (in chunks) -> epsilon-greedy selection.
+    -> (actions (N,4), q_values (N,3)); numpy with envs.numpy_io, device tensors otherwise."""
+    model.eval()
+    io = envs.numpy_io
+    envs.numpy_io = False
+    try:
+        persp, pos, _ = envs.generatePerspective(dtype=dtype)
+        q = _forward_chunked(model, persp, chunk)
+        act, qv = envs.selectAction(q, epsilon, positions=pos)
+    finally:
+        envs.numpy_io = io
+    if io:
+        return act.cpu().numpy().astype(np.int64), qv.cpu().numpy()
+    return act, qv
+
+
+def segment_max(q_table, offsets, largest=None):
+    """out[i] = max of q_table[offsets[i]:offsets[i+1]] (0 for an empty slice); with ``largest``
+    (device int32[1]) the reference's zero padding is reproduced."""
+    n = int(offsets.numel()) - 1
+    out = torch.empty(n, dtype=torch.float32, device=q_table.device)
+    with torch.cuda.device(q_table.device):
+        check(_lib.load().tq_segment_max(_ptr(q_table.contiguous()), _ptr(offsets), n, _ptr(largest), _ptr(out),
+                                         _stream()))
+    return out
+
+
+def predictMaxOptimized(model, batch_state, grid_shift, system_size, device, chunk=1 << 16):
+    """util_learner.py:48-111: max Q-value of every state of the batch (0 for terminal states),
+    perspectives generated and reduced on the device.  -> float32 tensor (n,) on ``device``."""
+    model.eval()
+    persp, pos, counts = generatePerspectiveBatch(grid_shift, system_size, batch_state, device=device)
+    offsets = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=persp.device)
+    torch.cumsum(counts, 0, out=offsets[1:])
+    q = _forward_chunked(model, persp, chunk)
+    # the reference gives a terminal state one dummy perspective (:74-76), which counts for the padding
+    largest = torch.clamp(counts.max(), min=1).to(torch.int32).reshape(1)
+    return segment_max(q, offsets, largest)
+
+
+def evaluate(model, env, env_config, grid_shift, device, prediction_list_p_error, num_of_episodes=1,
+             num_actions=3, epsilon=0.0, num_of_steps=50, plot_one_episode=False, minimum_nbr_of_qubit_errors=0,
+             seed=0, chunk=1 << 16):
+    """evaluation.py:10-124 with the episodes of one p_error run side by side as one EnvSet.
+    -> (error_corrected_list, ground_state_list, average_number_of_steps_list, mean_q_list, failed_syndroms)."""
+    if minimum_nbr_of_qubit_errors:
+        raise ValueError("minimum_nbr_of_qubit_errors != 0 is not supported")
+    model.to(device)
+    model.eval()
+    size = int(env_config["size"])
+    if int(grid_shift) != size // 2:
+        raise ValueError("grid_shift must be int(size/2)")
+    k = len(prediction_list_p_error)
+    corrected, ground, steps_avg, mean_q = np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
+    failed = []
+    for i, p in enumerate(prediction_list_p_error):
+        cfg = {"size": size, "min_qubit_errors": 0, "p_error": float(p)}
+        envs = EnvSet(ToricEnv(cfg, device=device, seed=seed + i), num_of_episodes, device=device, numpy_io=False)
+        envs.resetAll()
+        init_q = envs.getQubits().clone()
+        done = torch.zeros(num_of_episodes, dtype=torch.bool, device=envs.device)
+        n_steps = torch.zeros(num_of_episodes, dtype=torch.int64, device=envs.device)
+        q_sum = torch.zeros((), dtype=torch.float64, device=envs.device)
+        q_cnt = torch.zeros((), dtype=torch.int64, device=envs.device)
+        for _ in range(int(num_of_steps)):
+            act, qv = selectActionBatch(envs, model, epsilon, chunk=chunk)     # op 0 for solved lattices
+            live = ~done
+            chosen = torch.gather(qv, 1, (act[:, 3].long() - 1).clamp(min=0).unsqueeze(1)).squeeze(1)
+            q_sum += (chosen.double() * live).sum()
+            q_cnt += live.sum()
+            n_steps += live
+            _, _, term, _ = envs.step(act)
+            done = done | term.bool()
+            if bool(done.all()):
+                break
+        gs = envs.evalGroundState().bool()
+        corrected[i] = float(done.double().mean())
+        ground[i] = float(gs.double().mean())
+        steps_avg[i] = np.round(float(n_steps.double().mean()), 1)
+        mean_q[i] = np.round(float(q_sum / q_cnt.clamp(min=1)), 3)
+        bad = (~done) | (~gs)
+        if bool(bad.any()):
+            fq = envs.getQubits()[bad].cpu().numpy()
+            for a, b in zip(init_q[bad].cpu().numpy(), fq):
+                failed.append(a)
+                failed.append(b)
+        envs.check()
+        envs.close()
+    return corrected, ground, steps_avg, mean_q, failed

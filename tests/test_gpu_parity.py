@@ -225,6 +225,15 @@ def test_line_ownership_with_empty_and_tiny_lattices(T, d, dtype):
     offs = torch.empty(n + 1, dtype=torch.int64, device=per.device)
     _lib.check(L.tq_states_persp_count(d, n, C.c_void_p(dev_st.data_ptr()), None, C.c_void_p(offs.data_ptr()), None))
     code = {torch.float32: 0, torch.float16: 1, torch.uint8: 3}[dtype]
+    pflat = torch.full((P * 3 + 64,), -5, dtype=torch.int32, device=per.device)
+    _lib.check(L.tq_states_persp_write(d, n, C.c_void_p(dev_st.data_ptr()), C.c_void_p(offs.data_ptr()),
+                                       C.c_void_p(flat.data_ptr()), C.c_void_p(pflat.data_ptr()), P, code, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(flat[:P * nq].float().cpu().numpy(), bp.astype(np.float32).reshape(-1))
+    assert bool((flat[P * nq:] == 7).all())
+    assert np.array_equal(pflat[:P * 3].cpu().numpy(), bpos.reshape(-1)) and bool((pflat[P * 3:] == -5).all())
+    # a stack without positions
+    flat.fill_(7)
     _lib.check(L.tq_states_persp_write(d, n, C.c_void_p(dev_st.data_ptr()), C.c_void_p(offs.data_ptr()),
                                        C.c_void_p(flat.data_ptr()), None, P, code, None))
     torch.cuda.synchronize()

@@ -590,12 +590,27 @@ __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restr
     const uint16_t* __restrict__ hw = hits[wave];
     const uint8_t* __restrict__ cw = cellv[wave];
 
-    if (pos) {                                               // positions (P,3): (layer,row,col) of each hit
-        for (int k = lane; k < 3 * n; k += 64) {
-            const int hidx = k / 3, comp = k - 3 * hidx;
-            const int h = hw[hidx] / NQ;
-            const int l = h >= DD, rem = h - l * DD, row = rem / D, col = rem - row * D;
-            pos[off * 3 + k] = comp == 0 ? l : (comp == 1 ? row : col);
+    // positions (P,3) i32: (layer,row,col) of each hit.  Same ownership rule on its own 128-byte
+    // lines (32 dwords): whole lines inside the lattice's [plo, phi) by 16-byte stores here, the
+    // mixed last line further down together with the stack's.
+    const int64_t plo = off * 3, phi = plo + 3 * n;
+    const int64_t PA = (plo + 31) / 32 * 32, PF = phi / 32 * 32;
+    auto pos_value = [&](int h, int comp) -> int {           // h = flat qubit index of the hit
+        const int l = h >= DD, rem = h - l * DD, row = rem / D, col = rem - row * D;
+        return comp == 0 ? l : (comp == 1 ? row : col);
+    };
+    if (pos && PF > PA) {
+        const int n_g = (int)((PF - PA) / 4);
+        int4* __restrict__ pseg = reinterpret_cast<int4*>(pos + PA);
+        for (int g = lane; g < n_g; g += 64) {
+            const int k0 = (int)(PA - plo) + 4 * g;
+            int o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j, hidx = k / 3;
+                o[j] = pos_value(hw[hidx] / NQ, k - 3 * hidx);
+            }
+            pseg[g] = make_int4(o[0], o[1], o[2], o[3]);
         }
     }
 
@@ -650,14 +665,23 @@ __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restr
         }
     }
 
-    // ---- the line [F, F+LE) when the segment ends inside it (F >= lo: its start is ours)
-    if (F >= lo && F < hi && lane < 32) {
-        const int64_t total_end = offsets[N] * NQ;
-        const int64_t cap_end = capacity * NQ;
-        const int64_t limit = total_end < cap_end ? total_end : cap_end;      // nothing is written at or beyond it
-        const int64_t line_end = F + LE;
-        const int64_t x0 = F + lane * EPW;                   // this lane's dword = elements x0 .. x0+EPW-1
-        uint32_t word = 0;
+    // ---- mixed last lines: the stack line [F, F+LE) on lanes 0..31 and the positions line
+    // [PF, PF+32) on lanes 32..63, each present when the lattice's range ends inside a line that
+    // starts in it.  Their trailing elements belong to the lattices that follow: one wave-uniform
+    // walk over those lattices serves both.
+    const bool s_mixed = F >= lo && F < hi;
+    const bool p_mixed = pos != nullptr && PF >= plo && PF < phi;
+    if (!s_mixed && !p_mixed) return;
+    const int64_t p_total = offsets[N];
+    const int64_t p_cap = p_total < capacity ? p_total : capacity;    // perspectives that may be written
+    const int64_t s_limit = p_cap * NQ, p_limit = p_cap * 3;          // nothing is written at or beyond these
+    const int64_t s_line_end = F + LE, p_line_end = PF + 32;
+    const bool s_lane = s_mixed && lane < 32, p_lane = p_mixed && lane >= 32;
+    const int64_t x0 = F + lane * EPW;                       // stack: this lane's dword = elements x0 .. x0+EPW-1
+    const int64_t y = PF + (lane - 32);                      // positions: this lane's dword
+    uint32_t word = 0;
+    int pval = 0;
+    if (s_lane) {
 #pragma unroll
         for (int j = 0; j < EPW; ++j) {                      // own elements
             const int64_t x = x0 + j;
@@ -668,40 +692,53 @@ __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restr
                 word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
             }
         }
-        // elements of the lattices that follow, up to the end of the line (wave-uniform walk)
-        int64_t e2 = e + 1, pos2 = hi;
-        while (e2 < N && pos2 < line_end && pos2 < limit) {
-            typename L::B v2, p2, f0, f1;
+    }
+    if (p_lane && y < phi) {
+        const int k = (int)(y - plo), hidx = k / 3;
+        pval = pos_value(hw[hidx] / NQ, k - 3 * hidx);
+    }
+    int64_t e2 = e + 1, spos = hi, ppos = phi;
+    while (e2 < N && ((s_mixed && spos < s_line_end && spos < s_limit) || (p_mixed && ppos < p_line_end && ppos < p_limit))) {
+        typename L::B v2, p2, f0, f1;
 #pragma unroll
-            for (int k = 0; k < W; ++k) { v2.w[k] = vp[(int64_t)k * N + e2]; p2.w[k] = vp[((int64_t)W + k) * N + e2]; }
-            L::hit_masks(v2, p2, f0, f1);
-            const int n2 = f0.popc() + f1.popc();
-            const int64_t end2 = pos2 + (int64_t)n2 * NQ;
+        for (int k = 0; k < W; ++k) { v2.w[k] = vp[(int64_t)k * N + e2]; p2.w[k] = vp[((int64_t)W + k) * N + e2]; }
+        L::hit_masks(v2, p2, f0, f1);
+        const int n2 = f0.popc() + f1.popc();
+        const int64_t send = spos + (int64_t)n2 * NQ, pend = ppos + 3 * n2;
+        if (s_lane) {
 #pragma unroll
             for (int j = 0; j < EPW; ++j) {
                 const int64_t x = x0 + j;
-                if (x >= pos2 && x < end2) {
-                    const int rel = (int)(x - pos2);         // < LE
+                if (x >= spos && x < send) {
+                    const int rel = (int)(x - spos);         // < LE
                     const int pidx = rel / NQ, cell = rel - pidx * NQ;
                     const int src = lut[kth_hit<D>(f0, f1, pidx) * NQ + cell];
                     const uint32_t b = (uint32_t)(src >= DD ? p2.get(src - DD) : v2.get(src));
                     word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
                 }
             }
-            pos2 = end2;
-            ++e2;
         }
-        if (x0 + EPW <= limit) {
+        if (p_lane && y >= ppos && y < pend) {
+            const int k = (int)(y - ppos), hidx = k / 3;      // < 32
+            pval = pos_value(kth_hit<D>(f0, f1, hidx), k - 3 * hidx);
+        }
+        spos = send;
+        ppos = pend;
+        ++e2;
+    }
+    if (s_lane) {
+        if (x0 + EPW <= s_limit) {
             reinterpret_cast<uint32_t*>(out)[x0 / EPW] = word;
         } else {
 #pragma unroll
             for (int j = 0; j < EPW; ++j)                    // the stack ends inside this dword
-                if (x0 + j < limit) {
+                if (x0 + j < s_limit) {
                     if (Enc::BITS == 16) reinterpret_cast<uint16_t*>(out)[x0 + j] = (uint16_t)(word >> (16 * j));
                     else if (Enc::BITS == 8) reinterpret_cast<uint8_t*>(out)[x0 + j] = (uint8_t)(word >> (8 * j));
                 }
         }
     }
+    if (p_lane && y < p_limit) pos[y] = pval;
 }
 
 // generateTransitionParallel on explicit u8 grids: one thread per output byte, the (hit, cell)

@@ -52,6 +52,11 @@ def parse():
     ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
+    ap.add_argument("--policy", default="explore", choices=["explore", "nn11"],
+                    help="explore: eps=1 selection in the fused kernel (default, the env path alone); "
+                         "nn11: NN_11 forward on the stack + device eps-greedy selection in the loop (NN-bound)")
+    ap.add_argument("--eps", type=float, default=0.1, help="epsilon of the nn11 policy")
+    ap.add_argument("--nn-dtype", default="bf16", choices=["f32", "bf16"], help="autocast dtype of the nn11 forward")
     return ap.parse_args()
 
 
@@ -100,11 +105,20 @@ def main():
     import toric_rl_decoder_amd as T
     from toric_rl_decoder_amd import gather as G
 
+    # Rehearsal on a one-GPU box: TORIC_DIST_BACKEND=gloo TORIC_SHARE_GPU=1 runs every rank on cuda:0
+    # with host-staged collectives (RCCL refuses two ranks on one device).  Real runs use nccl = RCCL.
+    backend = os.environ.get("TORIC_DIST_BACKEND", "nccl")
+    if os.environ.get("TORIC_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    red_dev = device if backend == "nccl" else torch.device("cpu")      # where scalar reductions live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     d, n, K, W = args.size, args.envs, args.steps, args.warmup
     nq = 2 * d * d
@@ -129,6 +143,13 @@ def main():
     if world > 1 and blocks is not None:
         tg = G.TransitionGather(blocks[0].nbytes, device, ring_slots=2)
 
+    model = None
+    if args.policy == "nn11":
+        from toric_rl_decoder_amd.policy import NN_11
+        torch.manual_seed(0)                                          # random-init weights of the NN_11 architecture
+        model = NN_11(d, 3).to(device).eval()
+        eps_t = torch.full((n,), args.eps, dtype=torch.float64, device=device)
+
     use_events = not args.no_events
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if use_events else []
 
@@ -141,7 +162,13 @@ def main():
             ev[timed_idx][1].record()
         p_log[t:t + 1].copy_(off[-1:])
         blk = None if blocks is None else blocks[(t // flush) & 1]
-        envs.actorStep(None, block=blk, slot=t % flush, want_actions=True)
+        act = None
+        if model is not None:                                         # configs[2] as written: stack -> NN_11 -> selection
+            P = int(off[-1].item())
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.nn_dtype == "bf16"):
+                q = torch.cat([model(stack[i:i + 32768]) for i in range(0, P, 32768)]).float()
+            act, _ = envs.selectAction(q, eps_t, positions=positions, offsets=off)
+        envs.actorStep(act, block=blk, slot=t % flush, want_actions=True)
         if tg is not None and (t + 1) % flush == 0:
             tg.gather(blk.buf)
 
@@ -163,12 +190,12 @@ def main():
     elapsed = time.perf_counter() - t0
     envs.check()                                                  # capacity / action latch
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     p_timed = p_log[W:].to(torch.float64)
-    p_sum = p_timed.sum().reshape(1)
+    p_sum = p_timed.sum().reshape(1).to(red_dev)
     if world > 1:
         dist.all_reduce(p_sum, op=dist.ReduceOp.SUM)
     total_steps = float(n) * world * K
@@ -180,11 +207,15 @@ def main():
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %d lattices/GPU, d=%d, p_error=%g; actor-loop pass = "
-                                   "perspective stack (%s) + positions -> eps=1 selection -> step -> transition "
-                                   "record -> auto-reset (max 75 steps/episode); policy NN excluded" %
-                                   (n, d, args.p_error, args.out_dtype),
+                                   "perspective stack (%s) + positions -> selection -> step -> transition "
+                                   "record -> auto-reset (max 75 steps/episode); %s" %
+                                   (n, d, args.p_error, args.out_dtype,
+                                    "policy NN excluded" if model is None else
+                                    "NN_11 (random init, %s) forward + eps=%g greedy selection IN the loop" % (args.nn_dtype, args.eps)),
+                       "policy": args.policy,
                        "envs_per_gpu": n, "d": d, "p_error": args.p_error, "out_dtype": args.out_dtype,
-                       "transitions": blocks is not None, "flush_steps": flush, "parallelism": "env-shard x%d" % world},
+                       "transitions": blocks is not None, "flush_steps": flush, "parallelism": "env-shard x%d" % world,
+                       "collective": None if world == 1 else "transition gather to rank 0 (%s) every %d steps" % (backend, flush)},
             "perspectives_per_sec": float(p_sum.item()) / elapsed,
         }
         if use_events:

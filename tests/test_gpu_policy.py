@@ -112,3 +112,46 @@ def test_evaluate_matches_oracle_loop(T):
         assert np.isclose(corrected[i], done.mean(), atol=1e-12) and np.isclose(ground[i], gs.mean(), atol=1e-12)
         assert steps_avg[i] == np.round(steps.mean(), 1) and mean_q[i] == np.round(qs / max(qn, 1), 3)
     assert len(failed) % 2 == 0
+
+
+def test_actor_loop_matches_oracle_loop(T):
+    """run_actor (Actor_mp.py:104-185 on the device) against the same loop spelled with oracle
+    calls: transitions of every buffer column and the priorities of computePrioritiesParallel."""
+    d, n, buf, flushes, max_steps = 5, 300, 4, 3, 6
+    env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+    gpu = T.EnvSet(env, n, seed=31, numpy_io=False, max_steps_per_episode=max_steps)
+    ora = O.OracleEnvSet(d, n, 0.1, seed=31)
+    model = IntQ(d, seed=2).to(gpu.device)
+    gpu.resetAll()
+    ora.resetAll()
+    eps = 0.3
+    gen = T.run_actor(gpu, model, flushes, buf, eps, discount_factor=0.95)
+    for f in range(flushes):
+        blk, prio = next(gen)
+        A = np.zeros((n, buf + 1, 4), np.int64)
+        Q = np.zeros((n, buf + 1, 3), np.float32)
+        R = np.zeros((n, buf + 1), np.float32)
+        trans = []
+        for t in range(buf + 1):
+            bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+            act, qv, _ = O.select_action_batch(oracle_q(model, bp), boff, bpos, eps, ora.seed, ora.env_ids,
+                                               ora.episodes, ora.steps)
+            prev = ora.states.copy()
+            _, rew, term, _ = ora.step(act)
+            trans.append(O.generate_transition_batch(act, prev, ora.states) + (rew.astype(np.float32), term))
+            A[:, t], Q[:, t], R[:, t] = act, qv, rew
+            idx = np.nonzero(term | (ora.steps > max_steps))[0]
+            if idx.size:
+                ora.resetTerminalEnvs(idx)
+        q_taken = np.take_along_axis(Q[:, :-1], (A[:, :-1, 3] - 1)[..., None], axis=2)[..., 0]
+        want = np.abs(R[:, :-1] + np.float32(0.95) * np.roll(Q, -1, axis=1)[:, :-1].max(axis=2) - q_taken)
+        assert np.allclose(prio.cpu().numpy(), want, rtol=0, atol=1e-6)
+        for t in (0, buf):
+            u = blk.unpack(first=t * n, count=n)
+            per, act_c, nper, rew, term = trans[t]
+            assert np.array_equal(u["perspective"].cpu().numpy(), per)
+            assert np.array_equal(u["next_perspective"].cpu().numpy(), nper)
+            assert np.array_equal(u["action"].cpu().numpy(), act_c)
+            assert np.array_equal(u["reward"].cpu().numpy(), rew)
+        assert np.array_equal(gpu.getStates().cpu().numpy(), ora.states)
+    gpu.close()

@@ -11,5 +11,7 @@ from .envset import (EnvSet, ToricEnv, TransitionBlock, generatePerspectiveBatch
 
 from .policy import NN_11, evaluate, predictMaxOptimized, segment_max, selectActionBatch  # noqa: F401,E402
 
-__all__ = ["NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "EnvSet", "ToricEnv", "TransitionBlock", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
+from .actor import computePrioritiesParallel, run_actor  # noqa: F401,E402
+
+__all__ = ["computePrioritiesParallel", "run_actor", "NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "EnvSet", "ToricEnv", "TransitionBlock", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
            "transition_dtype", "ToricEnvError", "build", "load", "LIB_PATH", "SUPPORTED_SIZES"]

@@ -13,6 +13,11 @@ Workload at N=1: BASELINE.json configs[2], the configuration the metric is quote
 65 536 lattices, d=7, p_error=0.10.  Inputs are resident in HBM when the timed region starts
 (the lattices live on the device; nothing crosses PCIe in the loop).
 
+Lattices are independent, so the batch is processed as --shards sub-shards on separate HIP streams:
+while one sub-shard's stack write saturates HBM, the other's latency-bound kernels (scan, fused
+step) run beside it.  Stack writes are ordered against each other with events (never concurrent),
+so the per-launch HIP-event timing of the write kernel stays clean.
+
 N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns a contiguous block of
 global env ids (weak scaling: 65 536 lattices per GPU); the only exchange is the gather of packed
 transition blocks to rank 0's HBM replay ring (RCCL over xGMI) every --flush steps, issued async
@@ -49,6 +54,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=2020)
     ap.add_argument("--out-dtype", default="f32", choices=["f32", "f16", "bf16", "u8"])
     ap.add_argument("--flush", type=int, default=8, help="steps per transition block / gather (N>1)")
+    ap.add_argument("--shards", type=int, default=1, help="independent sub-shards (HIP streams) per GPU")
     ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
@@ -92,6 +98,10 @@ def cpu_baseline(d, p, seed, budget_s):
     return out
 
 
+class Shard:
+    """One sub-shard of this GPU's lattices with its stream and its caller-owned output buffers."""
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,53 +134,70 @@ def main():
     nq = 2 * d * d
     tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "u8": torch.uint8}[args.out_dtype]
     esize = {"f32": 4, "f16": 2, "bf16": 2, "u8": 1}[args.out_dtype]
-
-    env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": 0, "p_error": args.p_error})
-    first, _ = G.shard_range(n * world, world, rank)
-    envs = T.EnvSet(env, n, device=device, seed=args.seed, first_env_id=first, numpy_io=False)
-    envs.resetAll()
-
-    # worst case every qubit is a hit (random exploration grows the defect density): size the stack
-    # for that -- 2.5 GB at d=7 f32, 6.9 GB at d=9 -- out of 288 GB of HBM
-    cap = n * nq
-    stack = torch.empty((cap, 2, d, d), dtype=tdtype, device=device)
-    positions = torch.empty((cap, 3), dtype=torch.int32, device=device)
-    p_log = torch.zeros(W + K, dtype=torch.int64, device=device)
-
+    S = max(1, args.shards)
+    if n % S:
+        sys.exit("--envs must be divisible by --shards")
+    ns = n // S
     flush = max(1, args.flush)
-    blocks = None if args.no_transitions else [envs.newTransitionBlock(steps=flush) for _ in range(2)]
-    tg = None
-    if world > 1 and blocks is not None:
-        tg = G.TransitionGather(blocks[0].nbytes, device, ring_slots=2)
+    use_events = not args.no_events
 
     model = None
     if args.policy == "nn11":
         from toric_rl_decoder_amd.policy import NN_11
         torch.manual_seed(0)                                          # random-init weights of the NN_11 architecture
         model = NN_11(d, 3).to(device).eval()
-        eps_t = torch.full((n,), args.eps, dtype=torch.float64, device=device)
 
-    use_events = not args.no_events
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if use_events else []
+    env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": 0, "p_error": args.p_error})
+    first, _ = G.shard_range(n * world, world, rank)
+    # worst case every qubit is a hit (exploration grows the defect density): size each stack for
+    # that -- 2.5 GB at d=7 f32, 6.9 GB at d=9 for 65 536 lattices -- out of 288 GB of HBM
+    cap = ns * nq
+    shards = []
+    for k in range(S):
+        sh = Shard()
+        sh.stream = torch.cuda.Stream(device=device) if S > 1 else torch.cuda.current_stream(device)
+        with torch.cuda.stream(sh.stream):
+            sh.envs = T.EnvSet(env, ns, device=device, seed=args.seed, first_env_id=first + k * ns, numpy_io=False)
+            sh.envs.resetAll()
+            sh.stack = torch.empty((cap, 2, d, d), dtype=tdtype, device=device)
+            sh.positions = torch.empty((cap, 3), dtype=torch.int32, device=device)
+            sh.offs = torch.zeros((W + K, ns + 1), dtype=torch.int64, device=device)     # one scan per step: P = row[-1]
+            sh.blocks = None if args.no_transitions else [sh.envs.newTransitionBlock(steps=flush) for _ in range(2)]
+            sh.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                     for _ in range(K)] if use_events else []
+            sh.wrote = torch.cuda.Event()
+            sh.eps = torch.full((ns,), args.eps, dtype=torch.float64, device=device) if model is not None else None
+        shards.append(sh)
+    torch.cuda.synchronize(device)
+    have_blocks = shards[0].blocks is not None
+    tg = None
+    if world > 1 and have_blocks:
+        tg = [G.TransitionGather(sh.blocks[0].nbytes, device, ring_slots=2) for sh in shards]
 
-    def one_step(t, timed_idx=None):
-        _, off = envs.perspectiveCounts()
-        if timed_idx is not None and use_events:
-            ev[timed_idx][0].record()
-        envs.writePerspectives(stack, positions, off)
-        if timed_idx is not None and use_events:
-            ev[timed_idx][1].record()
-        p_log[t:t + 1].copy_(off[-1:])
-        blk = None if blocks is None else blocks[(t // flush) & 1]
-        act = None
-        if model is not None:                                         # configs[2] as written: stack -> NN_11 -> selection
-            P = int(off[-1].item())
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.nn_dtype == "bf16"):
-                q = torch.cat([model(stack[i:i + 32768]) for i in range(0, P, 32768)]).float()
-            act, _ = envs.selectAction(q, eps_t, positions=positions, offsets=off)
-        envs.actorStep(act, block=blk, slot=t % flush, want_actions=True)
-        if tg is not None and (t + 1) % flush == 0:
-            tg.gather(blk.buf)
+    def one_step(k, t, timed_idx=None):
+        sh = shards[k]
+        with torch.cuda.stream(sh.stream):
+            envs, off = sh.envs, sh.offs[t]
+            envs.perspectiveCounts(off)
+            if S > 1:
+                sh.stream.wait_event(shards[(k - 1) % S].wrote)          # one stack write at a time
+            if timed_idx is not None and use_events:
+                sh.ev[timed_idx][0].record(sh.stream)
+            envs.writePerspectives(sh.stack, sh.positions, off)
+            if timed_idx is not None and use_events:
+                sh.ev[timed_idx][1].record(sh.stream)
+            if S > 1:
+                sh.wrote.record(sh.stream)
+            blk = sh.blocks[(t // flush) & 1] if have_blocks else None
+            act = None
+            if model is not None:                                     # configs[2] as written: stack -> NN_11 -> selection
+                P = int(off[-1].item())
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.nn_dtype == "bf16"):
+                    q = torch.cat([model(sh.stack[i:i + 32768]) for i in range(0, P, 32768)]).float()
+                act, _ = envs.selectAction(q, sh.eps, positions=sh.positions, offsets=off)
+            envs.actorStep(act, block=blk, slot=t % flush, want_actions=True)
+            if tg is not None and (t + 1) % flush == 0:
+                tg[k].gather(blk.buf)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -179,28 +206,35 @@ def main():
         torch.cuda.synchronize(device)
 
     for t in range(W):
-        one_step(t)
+        for k in range(S):
+            one_step(k, t)
     barrier()
     t0 = time.perf_counter()
-    for k in range(K):
-        one_step(W + k, k)
+    for i in range(K):
+        for k in range(S):
+            one_step(k, W + i, i)
     if tg is not None:
-        tg.wait()
+        for k, g in enumerate(tg):
+            with torch.cuda.stream(shards[k].stream):
+                g.wait()
     barrier()
     elapsed = time.perf_counter() - t0
-    envs.check()                                                  # capacity / action latch
+    for sh in shards:
+        sh.envs.check()                                               # capacity / action latch
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    p_timed = p_log[W:].to(torch.float64)
+    p_timed = torch.stack([sh.offs[W:, -1] for sh in shards]).to(torch.float64)       # (S, K) perspectives per launch
     p_sum = p_timed.sum().reshape(1).to(red_dev)
     if world > 1:
         dist.all_reduce(p_sum, op=dist.ReduceOp.SUM)
     total_steps = float(n) * world * K
 
     if rank == 0:
+        policy_txt = "policy NN excluded (eps=1 selection in the fused kernel)" if model is None else \
+            "NN_11 (random init, %s) forward + eps=%g greedy selection IN the loop" % (args.nn_dtype, args.eps)
         res = {
             "metric": "env steps/sec (batched) at d=%d p=%g" % (d, args.p_error),
             "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -209,37 +243,38 @@ def main():
             "config": {"workload": "BASELINE configs[2]: %d lattices/GPU, d=%d, p_error=%g; actor-loop pass = "
                                    "perspective stack (%s) + positions -> selection -> step -> transition "
                                    "record -> auto-reset (max 75 steps/episode); %s" %
-                                   (n, d, args.p_error, args.out_dtype,
-                                    "policy NN excluded" if model is None else
-                                    "NN_11 (random init, %s) forward + eps=%g greedy selection IN the loop" % (args.nn_dtype, args.eps)),
-                       "policy": args.policy,
-                       "envs_per_gpu": n, "d": d, "p_error": args.p_error, "out_dtype": args.out_dtype,
-                       "transitions": blocks is not None, "flush_steps": flush, "parallelism": "env-shard x%d" % world,
-                       "collective": None if world == 1 else "transition gather to rank 0 (%s) every %d steps" % (backend, flush)},
+                                   (n, d, args.p_error, args.out_dtype, policy_txt),
+                       "policy": args.policy, "envs_per_gpu": n, "d": d, "p_error": args.p_error,
+                       "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
+                       "streams_per_gpu": S, "parallelism": "env-shard x%d" % world,
+                       "collective": None if world == 1 else
+                       "transition gather to rank 0 (%s) every %d steps" % (backend, flush)},
             "perspectives_per_sec": float(p_sum.item()) / elapsed,
         }
         if use_events:
-            ms = np.array([a.elapsed_time(b) for a, b in ev])
+            ms = np.array([[a.elapsed_time(b) for a, b in sh.ev] for sh in shards])     # (S, K) launch durations
             p_mean = float(p_timed.mean().item())
-            alg = p_mean * (nq * esize + 12) + n * nq                  # P*(B_p+12) + N*2d^2
+            alg = p_mean * (nq * esize + 12) + ns * nq                 # P*(B_p+12) + N*2d^2, per launch
             achieved = alg / (ms.mean() * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
-                    if j.get("envs") == n and j.get("d") == d and j.get("out_dtype") == args.out_dtype:
+                    if j.get("envs") == ns and j.get("d") == d and j.get("out_dtype") == args.out_dtype:
                         traffic = j.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             res["roofline"] = {"bound": "hbm", "kernel": "k_persp_write", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                                "bytes_per_launch": alg, "avg_launch_ms": float(ms.mean()),
-                               "median_launch_ms": float(np.median(ms)), "perspectives_per_launch": p_mean}
+                               "median_launch_ms": float(np.median(ms)), "perspectives_per_launch": p_mean,
+                               "launches_per_step": S, "lattices_per_launch": ns}
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(d, args.p_error, args.seed, args.cpu_seconds)
         print(json.dumps(res), flush=True)
-    envs.close()
+    for sh in shards:
+        sh.envs.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -236,7 +236,8 @@ class EnvSet:
             return None
         if torch.is_tensor(x):
             return x.to(device=self.device, dtype=dtype).contiguous()
-        return torch.as_tensor(np.ascontiguousarray(x), device=self.device).to(dtype).contiguous()
+        x = np.array(x, copy=True) if isinstance(x, np.ndarray) and not x.flags.writeable else np.ascontiguousarray(x)
+        return torch.as_tensor(x, device=self.device).to(dtype).contiguous()
 
     def check(self):
         """Raise if a kernel latched an error (bad action / capacity).  Synchronises."""
@@ -327,8 +328,13 @@ class EnvSet:
         return out.cpu().numpy().astype(bool) if self.numpy_io else out
 
     # ------------------------------------------------------------------ perspectives
-    def perspectiveCounts(self):
-        """-> (counts i32[N], offsets i64[N+1]) device tensors; no synchronisation."""
+    def perspectiveCounts(self, offsets=None):
+        """-> (counts i32[N], offsets i64[N+1]) device tensors; no synchronisation.  ``offsets``:
+        optional caller-owned int64[N+1] tensor to receive the scan instead of the internal one."""
+        if offsets is not None:
+            if offsets.dtype != torch.int64 or offsets.numel() != self.no_envs + 1 or not offsets.is_contiguous():
+                raise ValueError("offsets must be a contiguous int64 tensor of no_envs + 1 elements")
+            self._offsets = offsets
         self._call(self._L.tq_persp_count, _ptr(self._counts), _ptr(self._offsets))
         return self._counts, self._offsets
 

@@ -212,6 +212,31 @@ __global__ __launch_bounds__(256) void k_transition(const uint64_t* __restrict__
     write_transition<D>(b, slot_base + e, v0, p0, v1, p1, a.x, a.y, a.z, a.w, 0.f, 0);
 }
 
+// env.reset for ONE lattice by a whole wavefront: lane c draws qubit c (same Philox counters as
+// reset_lattice, so bit-identical) and __ballot assembles the 64-bit plane words directly.  All 64
+// lanes must be active; env/episode/p are wave-uniform; the result is the same in every lane.
+template <int D>
+__device__ __forceinline__ void reset_lattice_wave(typename Lat<D>::State& s, uint64_t seed, uint32_t env,
+                                                   uint32_t episode, double p, int lane) {
+    using L = Lat<D>;
+    for (int r = 0; r < MAX_RESET_ROUNDS; ++r) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+#pragma unroll
+            for (int k = 0; k < L::W; ++k) {
+                const int c = 64 * k + lane;
+                const U4 w = draw(seed, env, episode, (uint32_t)r, DOMAIN_ERR, (uint32_t)(l * L::DD + c));
+                const bool err = (c < L::DD) && (u01(w.x) < p);
+                const uint32_t pauli = 1 + mulhi32(w.y, 3);
+                s.x[l].w[k] = __ballot(err && ((pauli == 1) | (pauli == 2)));
+                s.z[l].w[k] = __ballot(err && (pauli >> 1));
+            }
+        }
+        L::syndrome(s);
+        if (s.v.any() || s.p.any()) return;
+    }
+}
+
 // ------------------------------------------------------------------ fused actor step
 // Actor_mp.py:116-183 after the policy: step -> transition -> reset(terminal | too many steps)
 // -> perspective counts.  actions == nullptr: pure exploration (eps = 1) drawn in-kernel.
@@ -225,8 +250,12 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
                                                     int max_steps, uint64_t seed, int64_t first_env, int64_t N,
                                                     int* __restrict__ err) {
     using L = Lat<D>;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
+    // every lane stays alive to the end (the reset below is wave-cooperative); lanes past N work on a
+    // clamped copy of the last lattice and store nothing
+    const int64_t e_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = e_raw < N;
+    const int64_t e = valid ? e_raw : N - 1;
+    const int lane = threadIdx.x & 63;
     typename L::State s = load_state<D>(planes, N, e);
     uint32_t ep = episodes[e], st = steps[e];
     const uint32_t env = (uint32_t)(first_env + e);
@@ -236,7 +265,7 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
         const int4 a = reinterpret_cast<const int4*>(actions)[e];
         layer = a.x; row = a.y; col = a.z; op = a.w;
         ok = action_ok<D>(layer, row, col, op);
-        if (!ok && !action_noop(op)) atomicOr(err, ERR_ACTION);
+        if (!ok && !action_noop(op) && valid) atomicOr(err, ERR_ACTION);
     } else {
         // non-greedy branch of _selectActionBatch_prime (numba/util_actor.py:97-98)
         typename L::B e0, e1;
@@ -253,7 +282,7 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
             op = 1 + (int)mulhi32(w.z, 3);
         }
     }
-    if (actions_out) reinterpret_cast<int4*>(actions_out)[e] = make_int4(layer, row, col, op);
+    if (actions_out && valid) reinterpret_cast<int4*>(actions_out)[e] = make_int4(layer, row, col, op);
     const typename L::B v0 = s.v, p0 = s.p;
     const int before = v0.popc() + p0.popc();
     if (ok) L::apply(s, layer, row, col, op);
@@ -262,13 +291,16 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
     const int terminal = after == 0;
     const float reward = terminal ? terminal_reward : (float)(before - after);
     st += 1;
-    if (rewards) rewards[e] = reward;
-    if (terminals) terminals[e] = (uint8_t)terminal;
-    if (has_block && ok)
+    if (rewards && valid) rewards[e] = reward;
+    if (terminals && valid) terminals[e] = (uint8_t)terminal;
+    if (has_block && ok && valid)
         write_transition<D>(blk, slot_base + e, v0, p0, s.v, s.p, layer, row, col, op, reward, terminal);
-    // reset policy of the caller (Actor_mp.py:171-183)
-    if (terminal || st > (uint32_t)max_steps) {
-        double p = sched.p_default;
+    // reset policy of the caller (Actor_mp.py:171-183).  Few lanes of a wave reset in a given step, so
+    // the lanes that do are served one after another by the whole wave (98 Philox draws in two passes
+    // instead of a 98-iteration loop in one lane while 63 wait).
+    const bool need_reset = valid && (terminal || st > (uint32_t)max_steps);
+    double p = sched.p_default;
+    if (need_reset) {
         if (sched.strategy != 0) {
             double roof = p_roof[e] + sched.p_delta;
             roof = roof < sched.p_final ? roof : sched.p_final;
@@ -281,14 +313,22 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
                 p = sched.p_start + t;
             }
         }
-        reset_lattice<D>(s, seed, env, ep, p);
-        ep += 1;
-        st = 0;
     }
-    store_state<D>(planes, N, e, s);
-    episodes[e] = ep;
-    steps[e] = st;
-    counts[e] = L::persp_count(s.v, s.p);
+    uint64_t pending = __ballot(need_reset);
+    while (pending) {                                        // wave-uniform
+        const int src = (int)__ffsll((long long)pending) - 1;
+        pending &= pending - 1;
+        typename L::State fresh;
+        reset_lattice_wave<D>(fresh, seed, (uint32_t)__shfl((int)env, src, 64), (uint32_t)__shfl((int)ep, src, 64),
+                              __shfl(p, src, 64), lane);
+        if (lane == src) { s = fresh; ep += 1; st = 0; }
+    }
+    if (valid) {
+        store_state<D>(planes, N, e, s);
+        episodes[e] = ep;
+        steps[e] = st;
+        counts[e] = L::persp_count(s.v, s.p);
+    }
 }
 
 // ------------------------------------------------------------------ u8 views

@@ -13,10 +13,10 @@ Workload at N=1: BASELINE.json configs[2], the configuration the metric is quote
 65 536 lattices, d=7, p_error=0.10.  Inputs are resident in HBM when the timed region starts
 (the lattices live on the device; nothing crosses PCIe in the loop).
 
-Lattices are independent, so the batch is processed as --shards sub-shards on separate HIP streams:
-while one sub-shard's stack write saturates HBM, the other's latency-bound kernels (scan, fused
-step) run beside it.  Stack writes are ordered against each other with events (never concurrent),
-so the per-launch HIP-event timing of the write kernel stays clean.
+Optional (--shards S > 1, default 1): lattices are independent, so the batch can be processed as S
+sub-shards on separate HIP streams, one shard's latency-bound kernels (scan, fused step) running
+beside another's stack write; writes are ordered against each other with events so their HIP-event
+timing stays clean.  Measured slower than one stream, hence off by default.
 
 N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns a contiguous block of
 global env ids (weak scaling: 65 536 lattices per GPU); the only exchange is the gather of packed
@@ -33,8 +33,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes), before HIP initialises
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -205,6 +207,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    if tg is not None:        # RCCL sets its communicator up lazily: pay for that before anything is timed
+        for k, g in enumerate(tg):
+            g.gather(shards[k].blocks[1].buf)
+            g.wait()
+    barrier()
     for t in range(W):
         for k in range(S):
             one_step(k, t)

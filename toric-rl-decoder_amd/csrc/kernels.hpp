@@ -9,7 +9,8 @@
 // Two kernel shapes:
 //   * env dynamics (reset / step / transition / fused actor step): ONE THREAD PER LATTICE.
 //     In bit-plane form a whole-lattice syndrome is ~20 shifts/xors, so there is nothing to
-//     share between lanes; 65 536 lattices = 1 024 wavefronts.
+//     share between lanes; 65 536 lattices = 1 024 wavefronts.  (Exception: the few resets inside
+//     the fused step are served by the whole wave, one qubit per lane, planes built by __ballot.)
 //   * perspective stack write (the HBM-bound kernel): ONE WAVEFRONT PER LATTICE.  The hit list,
 //     the syndrome cells and the (hit, cell) -> source-cell table sit in LDS; periodic shifts and
 //     the layer-1 rotation are LDS index lookups; every lane stores 16 B, so one wave

@@ -93,6 +93,20 @@ struct PerrSchedule {
     double p_default, p_start, p_final, p_delta;
 };
 
+// First pass of the exclusive scan, folded into the kernels that produce the hit counts: every
+// 256-thread block of an all-lattice kernel leaves the sum of its 256 counts in part256[blockIdx.x].
+// All 256 threads must call it (threads past N pass 0).
+constexpr int PART_BLOCK = 256;
+__device__ __forceinline__ void block_count_partial(int my_count, int64_t* __restrict__ part256) {
+    __shared__ int ws_[4];
+    int s = my_count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) ws_[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part256[blockIdx.x] = (int64_t)ws_[0] + ws_[1] + ws_[2] + ws_[3];
+}
+
 // ------------------------------------------------------------------ reset
 // env.reset(p_error) per lattice (EnvSet.py:19-36).  idx == nullptr: all lattices.
 template <int D>
@@ -100,20 +114,25 @@ __global__ __launch_bounds__(256) void k_reset(uint64_t* __restrict__ planes, ui
                                                uint32_t* __restrict__ steps, int32_t* __restrict__ counts,
                                                const int32_t* __restrict__ idx, int n_idx,
                                                const double* __restrict__ p_err, double p_default,
-                                               uint64_t seed, int64_t first_env, int64_t N) {
+                                               uint64_t seed, int64_t first_env, int64_t N,
+                                               int64_t* __restrict__ part256) {
     using L = Lat<D>;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = idx ? n_idx : N;
-    if (t >= m) return;
-    const int64_t e = idx ? idx[t] : t;
-    if (e < 0 || e >= N) return;
-    typename L::State s;
-    const uint32_t ep = episodes[e];
-    reset_lattice<D>(s, seed, (uint32_t)(first_env + e), ep, p_err ? p_err[t] : p_default);
-    store_state<D>(planes, N, e, s);
-    episodes[e] = ep + 1;
-    steps[e] = 0;
-    counts[e] = L::persp_count(s.v, s.p);
+    int64_t e = -1;
+    if (t < m) e = idx ? idx[t] : t;
+    int cnt = 0;
+    if (e >= 0 && e < N) {
+        typename L::State s;
+        const uint32_t ep = episodes[e];
+        reset_lattice<D>(s, seed, (uint32_t)(first_env + e), ep, p_err ? p_err[t] : p_default);
+        store_state<D>(planes, N, e, s);
+        episodes[e] = ep + 1;
+        steps[e] = 0;
+        cnt = L::persp_count(s.v, s.p);
+        counts[e] = cnt;
+    }
+    if (part256) block_count_partial(cnt, part256);          // all-lattice mode only (uniform branch)
 }
 
 // validated decode of action = [layer,row,col,op]
@@ -132,25 +151,29 @@ __global__ __launch_bounds__(256) void k_step(uint64_t* __restrict__ planes, uin
                                               const int32_t* __restrict__ actions, float* __restrict__ rewards,
                                               uint8_t* __restrict__ terminals, uint32_t* __restrict__ steps,
                                               int32_t* __restrict__ counts, float terminal_reward, int64_t N,
-                                              int* __restrict__ err) {
+                                              int* __restrict__ err, int64_t* __restrict__ part256) {
     using L = Lat<D>;
     constexpr int W = L::W;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    typename L::State s = load_state<D>(planes, N, e);
-    const int4 a = reinterpret_cast<const int4*>(actions)[e];
-    store_plane<W>(prev, 0, N, e, s.v);
-    store_plane<W>(prev, 1, N, e, s.p);
-    const int before = s.v.popc() + s.p.popc();
-    if (action_ok<D>(a.x, a.y, a.z, a.w)) L::apply(s, a.x, a.y, a.z, a.w);
-    else if (!action_noop(a.w)) atomicOr(err, ERR_ACTION);
-    L::syndrome(s);
-    const int after = s.v.popc() + s.p.popc();
-    store_state<D>(planes, N, e, s);
-    if (rewards) rewards[e] = after == 0 ? terminal_reward : (float)(before - after);
-    if (terminals) terminals[e] = after == 0;
-    steps[e] += 1;
-    counts[e] = L::persp_count(s.v, s.p);
+    int cnt = 0;
+    if (e < N) {
+        typename L::State s = load_state<D>(planes, N, e);
+        const int4 a = reinterpret_cast<const int4*>(actions)[e];
+        store_plane<W>(prev, 0, N, e, s.v);
+        store_plane<W>(prev, 1, N, e, s.p);
+        const int before = s.v.popc() + s.p.popc();
+        if (action_ok<D>(a.x, a.y, a.z, a.w)) L::apply(s, a.x, a.y, a.z, a.w);
+        else if (!action_noop(a.w)) atomicOr(err, ERR_ACTION);
+        L::syndrome(s);
+        const int after = s.v.popc() + s.p.popc();
+        store_state<D>(planes, N, e, s);
+        if (rewards) rewards[e] = after == 0 ? terminal_reward : (float)(before - after);
+        if (terminals) terminals[e] = after == 0;
+        steps[e] += 1;
+        cnt = L::persp_count(s.v, s.p);
+        counts[e] = cnt;
+    }
+    block_count_partial(cnt, part256);
 }
 
 // ------------------------------------------------------------------ packed transition block
@@ -249,7 +272,7 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
                                                     uint8_t* __restrict__ terminals, BlockView blk, int has_block,
                                                     int64_t slot_base, PerrSchedule sched, float terminal_reward,
                                                     int max_steps, uint64_t seed, int64_t first_env, int64_t N,
-                                                    int* __restrict__ err) {
+                                                    int* __restrict__ err, int64_t* __restrict__ part256) {
     using L = Lat<D>;
     // every lane stays alive to the end (the reset below is wave-cooperative); lanes past N work on a
     // clamped copy of the last lattice and store nothing
@@ -324,12 +347,14 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
                               __shfl(p, src, 64), lane);
         if (lane == src) { s = fresh; ep += 1; st = 0; }
     }
+    const int cnt = valid ? L::persp_count(s.v, s.p) : 0;
     if (valid) {
         store_state<D>(planes, N, e, s);
         episodes[e] = ep;
         steps[e] = st;
-        counts[e] = L::persp_count(s.v, s.p);
+        counts[e] = cnt;
     }
+    block_count_partial(cnt, part256);
 }
 
 // ------------------------------------------------------------------ u8 views
@@ -367,28 +392,33 @@ __global__ __launch_bounds__(256) void k_get_qubits(const uint64_t* __restrict__
 // u8 Pauli codes -> planes (+ syndrome, counts); thread per lattice.
 template <int D>
 __global__ __launch_bounds__(256) void k_set_qubits(uint64_t* __restrict__ planes, int32_t* __restrict__ counts,
-                                                    const uint8_t* __restrict__ q, int64_t N) {
+                                                    const uint8_t* __restrict__ q, int64_t N,
+                                                    int64_t* __restrict__ part256) {
     using L = Lat<D>;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    typename L::State s;
+    int cnt = 0;
+    if (e < N) {
+        typename L::State s;
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < 2; ++l) {
 #pragma unroll
-        for (int k = 0; k < L::W; ++k) {
-            uint64_t ax = 0, az = 0;
-            const int nb = (L::DD - 64 * k) < 64 ? (L::DD - 64 * k) : 64;
-            for (int bit = 0; bit < nb; ++bit) {
-                const int code = q[e * L::NQ + l * L::DD + 64 * k + bit];
-                ax |= (uint64_t)((code == 1) | (code == 2)) << bit;
-                az |= (uint64_t)((code >> 1) & 1) << bit;
+            for (int k = 0; k < L::W; ++k) {
+                uint64_t ax = 0, az = 0;
+                const int nb = (L::DD - 64 * k) < 64 ? (L::DD - 64 * k) : 64;
+                for (int bit = 0; bit < nb; ++bit) {
+                    const int code = q[e * L::NQ + l * L::DD + 64 * k + bit];
+                    ax |= (uint64_t)((code == 1) | (code == 2)) << bit;
+                    az |= (uint64_t)((code >> 1) & 1) << bit;
+                }
+                s.x[l].w[k] = ax; s.z[l].w[k] = az;
             }
-            s.x[l].w[k] = ax; s.z[l].w[k] = az;
         }
+        L::syndrome(s);
+        store_state<D>(planes, N, e, s);
+        cnt = L::persp_count(s.v, s.p);
+        counts[e] = cnt;
     }
-    L::syndrome(s);
-    store_state<D>(planes, N, e, s);
-    counts[e] = L::persp_count(s.v, s.p);
+    block_count_partial(cnt, part256);
 }
 // u8[n,2,d,d] syndromes -> V/P planes u64[2][W][n] (+ counts); for states outside a handle.
 template <int D>
@@ -449,9 +479,11 @@ __global__ __launch_bounds__(256) void k_block_unpack(BlockView b, int64_t first
 }
 
 // ------------------------------------------------------------------ exclusive scan of counts
-// Two-level scan, SCAN_CHUNK = 2048 counts per 256-thread workgroup (8 per thread, two int4
-// loads): k_scan_partials writes one sum per chunk; k_scan_final re-reads its chunk, adds the sums
-// of the chunks before it (<= N/2048 values, one strided wave reduction) and writes offsets.
+// Two-level scan.  Level 1: one sum per 256 counts (part256), left behind by the kernel that produced
+// the counts (block_count_partial) or, when lattices were reset by index, recomputed by
+// k_scan_partials.  Level 2 (k_scan_final): a 256-thread workgroup owns SCAN_CHUNK = 2048 counts
+// (8 per thread, two int4 loads), adds the partials before its chunk (<= N/256 values, one strided
+// wave reduction) and writes the offsets.
 constexpr int SCAN_CHUNK = 2048;
 
 __device__ __forceinline__ int64_t wave_sum64(int64_t x) {
@@ -471,18 +503,10 @@ __device__ __forceinline__ void scan_load8(const int32_t* __restrict__ counts, i
     }
 }
 
-__global__ __launch_bounds__(256) void k_scan_partials(const int32_t* __restrict__ counts, int64_t* __restrict__ partial,
+__global__ __launch_bounds__(256) void k_scan_partials(const int32_t* __restrict__ counts, int64_t* __restrict__ part256,
                                                        int64_t N) {
-    __shared__ int64_t ws[4];
-    int c[8];
-    scan_load8(counts, N, (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * 8, c);
-    int64_t s = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += c[k];
-    s = wave_sum64(s);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+    const int64_t e = (int64_t)blockIdx.x * PART_BLOCK + threadIdx.x;
+    block_count_partial(e < N ? counts[e] : 0, part256);
 }
 
 __global__ __launch_bounds__(256) void k_scan_final(const int32_t* __restrict__ counts, const int64_t* __restrict__ partial,
@@ -504,9 +528,9 @@ __global__ __launch_bounds__(256) void k_scan_final(const int32_t* __restrict__ 
         if (lane >= o) inc += t;
     }
     if (lane == 63) ws[wave] = inc;
-    if (wave == 0) {                                          // sum of the chunks before this one
+    if (wave == 0) {                                          // sum of the 256-count partials before this chunk
         int64_t b = 0;
-        for (int j = lane; j < (int)blockIdx.x; j += 64) b += partial[j];
+        for (int j = lane; j < (int)blockIdx.x * (SCAN_CHUNK / PART_BLOCK); j += 64) b += partial[j];
         b = wave_sum64(b);
         if (lane == 0) base_s = b;
     }

@@ -98,10 +98,12 @@ int get_lut(int dev, int d, hipStream_t stream, const uint8_t** out) {
     return TQ_OK;
 }
 
-int launch_scan(const int32_t* counts, int64_t* partial, int64_t* offsets, int32_t* counts_out, int64_t n,
-                hipStream_t stream) {
+int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int64_t* offsets, int32_t* counts_out,
+                int64_t n, hipStream_t stream) {
     const unsigned blocks = (unsigned)((n + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK);
-    hipLaunchKernelGGL(tq::k_scan_partials, dim3(blocks), dim3(256), 0, stream, counts, partial, n);
+    if (!partial_valid)
+        hipLaunchKernelGGL(tq::k_scan_partials, dim3((unsigned)((n + tq::PART_BLOCK - 1) / tq::PART_BLOCK)), dim3(256), 0,
+                           stream, counts, partial, n);
     hipLaunchKernelGGL(tq::k_scan_final, dim3(blocks), dim3(256), 0, stream, counts, (const int64_t*)partial, offsets,
                        counts_out, n);
     KCHECK();
@@ -147,7 +149,8 @@ struct tq_env {
     uint32_t* episodes;
     uint32_t* steps;
     int32_t* counts;
-    int64_t* partial;      // scan scratch: one sum per 2048 counts
+    int64_t* partial;      // level-1 sums of the scan: one per 256 counts
+    bool partial_valid;    // left current by the last all-lattice kernel (false after tq_reset_idx)
     double* p_roof;
     int* err;              // device error latch
     const uint8_t* lut;
@@ -199,7 +202,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc((void**)&h->episodes, N * 4);
     alloc((void**)&h->steps, N * 4);
     alloc((void**)&h->counts, N * 4 + 32);                      // +32: int4 tail loads of the scan stay in bounds
-    alloc((void**)&h->partial, ((N + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK) * 8);
+    alloc((void**)&h->partial, ((N + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8);
     alloc((void**)&h->p_roof, N * 8);
     alloc((void**)&h->err, 4);
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
@@ -248,10 +251,12 @@ int tq_size(const tq_env* h) { return h ? h->d : 0; }
 int tq_reset_all(tq_env* h, const double* p_err, void* stream_) {
     HANDLE(h);
 #define CALL(D) hipLaunchKernelGGL(tq::k_reset<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->episodes, \
-        h->steps, h->counts, (const int32_t*)nullptr, 0, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n)
+        h->steps, h->counts, (const int32_t*)nullptr, 0, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n, \
+        h->partial)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
+    h->partial_valid = true;
     return TQ_OK;
 }
 
@@ -260,10 +265,11 @@ int tq_reset_idx(tq_env* h, const int32_t* idx, int n_idx, const double* p_err, 
     if (n_idx < 0 || (n_idx > 0 && !idx)) return fail(TQ_E_INVALID, "bad idx / n_idx");
     if (n_idx == 0) return TQ_OK;
 #define CALL(D) hipLaunchKernelGGL(tq::k_reset<D>, grid1(n_idx, 256), dim3(256), 0, stream, h->planes, h->episodes, \
-        h->steps, h->counts, idx, n_idx, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n)
+        h->steps, h->counts, idx, n_idx, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n, (int64_t*)nullptr)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
+    h->partial_valid = false;
     return TQ_OK;
 }
 
@@ -271,10 +277,11 @@ int tq_step(tq_env* h, const int32_t* actions, float* rewards, uint8_t* terminal
     HANDLE(h);
     if (!actions) return fail(TQ_E_INVALID, "actions is NULL");
 #define CALL(D) hipLaunchKernelGGL(tq::k_step<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->prev, actions, \
-        rewards, terminals, h->steps, h->counts, (float)h->terminal_reward, (int64_t)h->n, h->err)
+        rewards, terminals, h->steps, h->counts, (float)h->terminal_reward, (int64_t)h->n, h->err, h->partial)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
+    h->partial_valid = true;
     return TQ_OK;
 }
 
@@ -317,10 +324,11 @@ int tq_get_qubits(tq_env* h, uint8_t* out, void* stream_) {
 int tq_set_qubits(tq_env* h, const uint8_t* qubits, void* stream_) {
     HANDLE(h);
     if (!qubits) return fail(TQ_E_INVALID, "qubits is NULL");
-#define CALL(D) hipLaunchKernelGGL(tq::k_set_qubits<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->counts, qubits, (int64_t)h->n)
+#define CALL(D) hipLaunchKernelGGL(tq::k_set_qubits<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->counts, qubits, (int64_t)h->n, h->partial)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
+    h->partial_valid = true;
     return TQ_OK;
 }
 
@@ -354,7 +362,8 @@ int tq_is_terminal(tq_env* h, uint8_t* out, void* stream_) {
 int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream_) {
     HANDLE(h);
     if (!offsets) return fail(TQ_E_INVALID, "offsets is NULL");
-    if (int rc = launch_scan(h->counts, h->partial, offsets, counts, h->n, stream)) return rc;
+    if (int rc = launch_scan(h->counts, h->partial, h->partial_valid, offsets, counts, h->n, stream)) return rc;
+    h->partial_valid = true;
     return TQ_OK;
 }
 
@@ -376,7 +385,7 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
     std::lock_guard<std::mutex> lock(c.mu);
     const size_t w = (size_t)(d * d + 63) / 64;
     const size_t cnt_bytes = (((size_t)n * 4 + 32 + 15) & ~(size_t)15);
-    const size_t part_bytes = (((size_t)n + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK) * 8;
+    const size_t part_bytes = (((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8;
     const size_t need = 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes + 16;
     if (c.ws_bytes < need) {
         if (c.ws) HIPCHECK(hipFree(c.ws));
@@ -404,7 +413,7 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-    if (int rc = launch_scan(cnt, part, offsets, counts, n, stream)) return rc;
+    if (int rc = launch_scan(cnt, part, false, offsets, counts, n, stream)) return rc;
     return TQ_OK;
 }
 
@@ -531,10 +540,11 @@ int tq_actor_step(tq_env* h, const int32_t* actions, int32_t* actions_out, float
     }
 #define CALL(D) hipLaunchKernelGGL(tq::k_actor_step<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->episodes, \
         h->steps, h->counts, h->p_roof, actions, actions_out, rewards, terminals, b, block ? 1 : 0, slot_base, h->sched, \
-        (float)h->terminal_reward, h->max_steps, h->seed, h->first_env, (int64_t)h->n, h->err)
+        (float)h->terminal_reward, h->max_steps, h->seed, h->first_env, (int64_t)h->n, h->err, h->partial)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
+    h->partial_valid = true;
     return TQ_OK;
 }
 

@@ -806,167 +806,6 @@ __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restr
     if (p_lane && y < p_limit) pos[y] = pval;
 }
 
-// ------------------------------------------------------------------ perspective stack write, windowed
-// Second shape of the same kernel (selected at run time, see launch_persp_write): PERSISTENT waves,
-// each streaming fixed, aligned 32 KB windows of the output (blocked-cyclic over the waves) instead
-// of one lattice.  Measured as a fill on the real segment table in one process
-// (tools/membench12.hip): 6.25-6.37 TB/s against 5.85 TB/s for one wave per lattice on a fast box,
-// equal on a slow one.  A window overlaps ~2 lattices: the wave finds the first through win_first
-// (k_window_map), then for each overlapping lattice rebuilds the per-lattice LDS tables and writes
-// the lattice's part of the window with the same 16-byte-store loop.  Window edges are line-aligned,
-// so lines are only ever shared between parts written by the SAME wave.
-__global__ __launch_bounds__(256) void k_window_map(const int64_t* __restrict__ offsets, int64_t N, int nq, int64_t we,
-                                                    int32_t* __restrict__ win_first, int64_t nwin_max) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    const int64_t lo = offsets[e] * nq, hi = offsets[e + 1] * nq;          // elements
-    for (int64_t w = (lo + we - 1) / we; w * we < hi && w < nwin_max; ++w) win_first[w] = (int32_t)e;
-}
-
-// lane `lane` writes 16-byte groups lane, lane+64, ... of n_groups groups starting at `seg`; the first
-// element of group 0 is element `rel0` of the lattice whose tables are hw / cw.
-template <int D, typename OutT>
-__device__ __forceinline__ void write_groups(char* __restrict__ seg, int n_groups, int rel0, const uint8_t* __restrict__ lut,
-                                             const uint16_t* __restrict__ hw, const uint8_t* __restrict__ cw, int lane) {
-    using Enc = OutEnc<OutT>;
-    constexpr int NQ = Lat<D>::NQ;
-    constexpr int VEC = 16 / (int)sizeof(OutT), EPW = 32 / Enc::BITS;
-    constexpr int STEP = 64 * VEC, DP = STEP / NQ, DC = STEP % NQ;
-    int pidx, cell;
-    {
-        const int rel = rel0 + lane * VEC;
-        pidx = rel / NQ;
-        cell = rel - pidx * NQ;
-    }
-    for (int gi = lane; gi < n_groups; gi += 64) {
-        uint32_t wd[4] = {0u, 0u, 0u, 0u};
-        int pp = pidx, cc = cell;
-#pragma unroll
-        for (int k = 0; k < VEC; k += 2) {                  // NQ and cell are even: a pair never straddles two perspectives
-            const unsigned src2 = *reinterpret_cast<const unsigned short*>(&lut[hw[pp] + cc]);
-            const uint32_t b0 = cw[src2 & 255], b1 = cw[src2 >> 8];
-            if (Enc::BITS == 32) {
-                wd[k] = __float_as_uint((float)b0);
-                wd[k + 1] = __float_as_uint((float)b1);
-            } else {
-                wd[k / EPW] |= ((0u - b0) & Enc::ONE) << ((k % EPW) * Enc::BITS);
-                wd[(k + 1) / EPW] |= ((0u - b1) & Enc::ONE) << (((k + 1) % EPW) * Enc::BITS);
-            }
-            if (k + 2 < VEC) {
-                cc += 2;
-                const bool wrap = cc >= NQ;
-                cc = wrap ? cc - NQ : cc;
-                pp = wrap ? pp + 1 : pp;
-            }
-        }
-        const u32x4 v4 = {wd[0], wd[1], wd[2], wd[3]};
-        *reinterpret_cast<u32x4*>(seg + (uint32_t)gi * 16u) = v4;
-        cell += DC;
-        pidx += DP;
-        const bool wrap = cell >= NQ;
-        cell = wrap ? cell - NQ : cell;
-        pidx = wrap ? pidx + 1 : pidx;
-    }
-}
-
-template <int D, typename OutT, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_persp_write_win(const uint64_t* __restrict__ vp, int64_t N,
-                                                             const int64_t* __restrict__ offsets, OutT* __restrict__ out,
-                                                             int32_t* __restrict__ pos, int64_t capacity,
-                                                             const uint8_t* __restrict__ lut_g, int* __restrict__ err,
-                                                             const int32_t* __restrict__ win_first, int64_t WE) {
-    using L = Lat<D>;
-    using Enc = OutEnc<OutT>;
-    constexpr int DD = L::DD, NQ = L::NQ, W = L::W;
-    constexpr int WAVES = THREADS / 64;
-    constexpr int VEC = 16 / (int)sizeof(OutT);
-    constexpr int LUT_BYTES = (NQ * NQ + 15) & ~15;
-    constexpr int NQP = (NQ + 3) & ~3;
-    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
-    __shared__ uint8_t cellv[WAVES][NQP];
-    __shared__ uint16_t hits[WAVES][NQP];
-    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
-        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
-    __syncthreads();
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint16_t* __restrict__ hw = hits[wave];
-    const uint8_t* __restrict__ cw = cellv[wave];
-    const int64_t p_total = offsets[N];
-    const int64_t p_cap = p_total < capacity ? p_total : capacity;    // perspectives that fit the caller's buffers
-    if (p_total > capacity && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, ERR_CAPACITY);
-    const int64_t limit = p_cap * NQ;                                 // elements; nothing is written at or beyond it
-    const int64_t nwin = (limit + WE - 1) / WE;
-    const int64_t stride = (int64_t)gridDim.x * WAVES;
-    auto element = [&](int rel) -> uint32_t {                         // value bit of element `rel` of the current lattice
-        const int pidx = rel / NQ, cell = rel - pidx * NQ;
-        return cw[lut[hw[pidx] + cell]];
-    };
-    auto store_el = [&](int64_t x, uint32_t b) {
-        if (Enc::BITS == 32) reinterpret_cast<uint32_t*>(out)[x] = (0u - b) & Enc::ONE;
-        else if (Enc::BITS == 16) reinterpret_cast<uint16_t*>(out)[x] = (uint16_t)((0u - b) & Enc::ONE);
-        else reinterpret_cast<uint8_t*>(out)[x] = (uint8_t)b;
-    };
-    for (int64_t w = (int64_t)blockIdx.x * WAVES + wave; w < nwin; w += stride) {
-        const int64_t wb = w * WE, we = wb + WE < limit ? wb + WE : limit;
-        int64_t e = win_first[w];
-        int64_t off = offsets[e];
-        while (e < N) {                                               // wave-uniform walk over the lattices of the window
-            const int64_t lo = off * NQ;
-            if (lo >= we) break;
-            typename L::B v, p, e0, e1;
-#pragma unroll
-            for (int k = 0; k < W; ++k) { v.w[k] = vp[(int64_t)k * N + e]; p.w[k] = vp[((int64_t)W + k) * N + e]; }
-            L::hit_masks(v, p, e0, e1);
-            const int n0 = e0.popc();
-            const int n = n0 + e1.popc();
-            if (n > 0) {
-                for (int c = lane; c < NQ; c += 64) {
-                    const int l = c >= DD, bit = c - l * DD;
-                    cellv[wave][c] = (uint8_t)(l ? p.get(bit) : v.get(bit));
-                    const int is_hit = l ? e1.get(bit) : e0.get(bit);
-                    if (is_hit) hits[wave][l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint16_t)(c * NQ);
-                }
-                wave_lds_sync();
-                const int64_t hi = lo + (int64_t)n * NQ;
-                if (pos && lo >= wb) {                                // the lattice starts in this window: its positions
-                    const int64_t plo = off * 3;
-                    const int64_t phi = (off + n <= p_cap ? off + n : p_cap) * 3;
-                    const int64_t pg0 = (plo + 3) / 4, pg1 = phi / 4;
-                    auto pos_value = [&](int k) -> int {
-                        const int hidx = k / 3, comp = k - 3 * hidx, h = hw[hidx] / NQ;
-                        const int l = h >= DD, rem = h - l * DD, row = rem / D, col = rem - row * D;
-                        return comp == 0 ? l : (comp == 1 ? row : col);
-                    };
-                    for (int64_t g = pg0 + lane; g < pg1; g += 64) {
-                        const int k0 = (int)(g * 4 - plo);
-                        reinterpret_cast<int4*>(pos)[g] = make_int4(pos_value(k0), pos_value(k0 + 1), pos_value(k0 + 2), pos_value(k0 + 3));
-                    }
-                    if (pg1 > pg0) {
-                        if (lane < 4 && plo + lane < pg0 * 4) pos[plo + lane] = pos_value(lane);
-                        if (lane >= 32 && lane < 36 && pg1 * 4 + (lane - 32) < phi) pos[pg1 * 4 + (lane - 32)] = pos_value((int)(pg1 * 4 - plo) + lane - 32);
-                    } else if (plo + lane < phi) {                    // fewer than two groups: lanes 0..6 cover it
-                        pos[plo + lane] = pos_value(lane);
-                    }
-                }
-                const int64_t A = lo > wb ? lo : wb, B = hi < we ? hi : we;       // this lattice's part of the window
-                const int64_t g0 = (A + VEC - 1) / VEC, g1 = B / VEC;
-                if (g1 > g0) {
-                    write_groups<D, OutT>(reinterpret_cast<char*>(out + g0 * VEC), (int)(g1 - g0), (int)(g0 * VEC - lo), lut, hw, cw, lane);
-                    if (lane < VEC && A + lane < g0 * VEC) store_el(A + lane, element((int)(A - lo) + lane));
-                    if (lane >= 32 && lane - 32 < VEC && g1 * VEC + (lane - 32) < B)
-                        store_el(g1 * VEC + (lane - 32), element((int)(g1 * VEC - lo) + lane - 32));
-                } else if (A + lane < B) {                            // part shorter than two groups (< 2*VEC <= 32 elements)
-                    store_el(A + lane, element((int)(A - lo) + lane));
-                }
-                wave_lds_sync();
-            }
-            off += n;
-            ++e;
-        }
-    }
-}
-
 // generateTransitionParallel on explicit u8 grids: one thread per output byte, the (hit, cell)
 // -> source-cell table does shift_state + rotate_state in one lookup; loads and stores coalesced.
 template <int D>

@@ -110,40 +110,14 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
     return TQ_OK;
 }
 
-// Shape of the stack write: 0 = one wavefront per lattice (workgroups dispatched per 4 lattices),
-// 1 = persistent wavefronts streaming aligned 32 KB windows (needs win_first scratch).  Selected per
-// process with TQ_WRITE_MODE (default below); both produce identical bytes.
-constexpr int64_t kWindowBytes = 32768;
-int write_mode() {
-    static const int mode = getenv("TQ_WRITE_MODE") ? atoi(getenv("TQ_WRITE_MODE")) : 0;
-    return mode;
-}
-int64_t window_slots(int64_t n, int d) {                     // win_first entries for the worst case (every qubit a hit, f32)
-    const int64_t nq = 2 * d * d;
-    return n * nq * nq / (kWindowBytes / 4) + 2;
-}
-
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
-                         int64_t capacity, const uint8_t* lut, int* err, int num_cus, int32_t* win_first,
-                         hipStream_t stream) {
+                         int64_t capacity, const uint8_t* lut, int* err, hipStream_t stream) {
     constexpr int THREADS = D <= 7 ? 256 : (D == 9 ? 512 : 1024);
     constexpr int WAVES = THREADS / 64;
-    if (write_mode() == 1 && win_first) {
-        const int64_t we = kWindowBytes / (int64_t)sizeof(OutT);
-        const int64_t nwin_max = window_slots(n, D);
-        hipLaunchKernelGGL(tq::k_window_map, grid1(n, 256), dim3(256), 0, stream, offsets, n, 2 * D * D, we, win_first, nwin_max);
-        // A persistent, statically assigned grid must be fully resident.  The kernel needs 97-112 SGPRs,
-        // which admits 6 waves per SIMD (MI355X_MICROARCH.md, Residency): 6 / 3 / 1 workgroups per CU.
-        static const int wgs_env = getenv("TQ_WRITE_WGS") ? atoi(getenv("TQ_WRITE_WGS")) : 0;
-        const int per_cu = wgs_env > 0 ? wgs_env : (6 / (THREADS / 256) > 0 ? 6 / (THREADS / 256) : 1);
-        const int64_t resident = (int64_t)num_cus * per_cu;
-        hipLaunchKernelGGL((tq::k_persp_write_win<D, OutT, THREADS>), dim3((unsigned)resident), dim3(THREADS), 0, stream,
-                           vp, n, offsets, (OutT*)out, pos, capacity, lut, err, (const int32_t*)win_first, we);
-        KCHECK();
-        return TQ_OK;
-    }
-    // one lattice per wave: the hardware dispatcher balances the variable-size lattices
+    // One lattice per wave; the hardware dispatcher balances the variable-size lattices.  Persistent
+    // waves (static or dynamic), fixed aligned windows and cooperative workgroups were all measured
+    // and are slower or equal in the real kernel (git history).
     const int64_t blocks = (n + WAVES - 1) / WAVES;
     hipLaunchKernelGGL((tq::k_persp_write<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
                        offsets, (OutT*)out, pos, capacity, lut, err);
@@ -153,13 +127,12 @@ int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, 
 
 template <int D>
 int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
-                       int64_t capacity, int dtype, const uint8_t* lut, int* err, int num_cus, int32_t* win_first,
-                       hipStream_t stream) {
+                       int64_t capacity, int dtype, const uint8_t* lut, int* err, hipStream_t stream) {
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, lut, err, num_cus, win_first, stream);
-        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, lut, err, num_cus, win_first, stream);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, lut, err, num_cus, win_first, stream);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, lut, err, num_cus, win_first, stream);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, lut, err, stream);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, lut, err, stream);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, lut, err, stream);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, lut, err, stream);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -180,7 +153,6 @@ struct tq_env {
     int32_t* counts;
     int64_t* partial;      // level-1 sums of the scan: one per 256 counts
     bool partial_valid;    // left current by the last all-lattice kernel (false after tq_reset_idx)
-    int32_t* win_first;    // window -> first lattice map of the windowed stack write
     double* p_roof;
     int* err;              // device error latch
     const uint8_t* lut;
@@ -234,7 +206,6 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc((void**)&h->counts, N * 4 + 32);                      // +32: int4 tail loads of the scan stay in bounds
     alloc((void**)&h->partial, ((N + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8);
     alloc((void**)&h->p_roof, N * 8);
-    alloc((void**)&h->win_first, (size_t)window_slots(n_envs, d) * 4);
     alloc((void**)&h->err, 4);
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
@@ -247,7 +218,7 @@ int tq_destroy(tq_env* h) {
     if (!h) return TQ_OK;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->planes); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
-    (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->win_first); (void)hipFree(h->err);
+    (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->err);
     delete h;
     return TQ_OK;
 }
@@ -404,22 +375,20 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
     if (!offsets || !out) return fail(TQ_E_INVALID, "offsets / out is NULL");
     if (capacity < 0) return fail(TQ_E_INVALID, "negative capacity");
     const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->lut, h->err, h->num_cus, h->win_first, stream)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->lut, h->err, stream)) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;
 }
 
 // ---- stateless variants (states outside a handle) -------------------------------------------
-static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int** err,
-                          int32_t** win_first = nullptr) {
+static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int** err) {
     DeviceCtx& c = g_ctx[dev];
     std::lock_guard<std::mutex> lock(c.mu);
     const size_t w = (size_t)(d * d + 63) / 64;
     const size_t cnt_bytes = (((size_t)n * 4 + 32 + 15) & ~(size_t)15);
     const size_t part_bytes = (((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8;
-    const size_t win_bytes = ((size_t)window_slots(n, d) * 4 + 15) & ~(size_t)15;
-    const size_t need = 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes + win_bytes + 16;
+    const size_t need = 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes + 16;
     if (c.ws_bytes < need) {
         if (c.ws) HIPCHECK(hipFree(c.ws));
         c.ws = nullptr; c.ws_bytes = 0;
@@ -430,7 +399,6 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
     *vp = (uint64_t*)c.ws;
     *counts = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8);
     *partial = (int64_t*)((char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes);
-    if (win_first) *win_first = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes);
     *err = (int*)((char*)c.ws + need - 16);
     return TQ_OK;
 }
@@ -460,13 +428,13 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut;
     if (int rc = get_lut(dev, d, stream, &lut)) return rc;
-    uint64_t* vp; int32_t* cnt; int64_t* part; int* err; int32_t* winf;
-    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err, &winf)) return rc;
+    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
 #define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, (int32_t*)nullptr, (int64_t)n)
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, lut, err, g_ctx[dev].num_cus, winf, stream)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, lut, err, stream)) return rc
     DISPATCH_D(d, CALL)
 #undef CALL
     return TQ_OK;

@@ -124,6 +124,10 @@ int tq_select_action(tq_env* h, const float* q_table, const int64_t* offsets,
                      const int32_t* positions, const double* eps, int32_t* actions,
                      float* q_values, void* stream);
 
+/* Reads and clears the calling device's error latch of the tq_states_* entry points (synchronises
+ * `stream`): 0, TQ_E_ACTION or TQ_E_CAPACITY. */
+int tq_states_check(void* stream);
+
 /* predictMaxOptimized's reduction (util_learner.py:96-110): out[i] = max over the (n_i,3) slice of
  * q_table, 0 for states without perspectives; `largest` = device i32[1] holding the longest slice
  * length reproduces the reference's zero padding (shorter slices get max(max_q, 0)); NULL = plain max. */

@@ -259,6 +259,11 @@ def test_bad_actions_and_capacity_are_reported(T):
         gpu.resetTerminalEnvs([0, 0])
     with pytest.raises(ValueError):
         gpu.resetTerminalEnvs([n])
+    st = np.zeros((4, 2, d, d), np.uint8)
+    with pytest.raises(ValueError):                        # stateless drop-in reports bad actions too
+        T.generateTransitionParallel(np.array([[0, 0, 0, 1], [2, 0, 0, 1], [0, 0, 0, 1], [0, 0, 0, 1]]), np.zeros(4), st, st,
+                                     np.zeros(4, bool), d // 2)
+    T.generateTransitionParallel(np.array([[0, 0, 0, 1]] * 4), np.zeros(4), st, st, np.zeros(4, bool), d // 2)
     cnt, off = gpu.perspectiveCounts()
     P = int(off[-1].item())
     small = torch.zeros((P - 1, 2, d, d), dtype=torch.float32, device=gpu.device)

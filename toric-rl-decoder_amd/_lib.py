@@ -41,6 +41,7 @@ SYMBOLS = [
     ("tq_states_persp_count", _i, [_i, _i, _vp, _vp, _vp, _vp]),
     ("tq_states_persp_write", _i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     ("tq_select_action", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("tq_states_check", _i, [_vp]),
     ("tq_segment_max", _i, [_vp, _vp, _i, _vp, _vp, _vp]),
     ("tq_transition_write", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("tq_states_transition", _i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

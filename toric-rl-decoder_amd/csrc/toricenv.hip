@@ -48,6 +48,7 @@ int size_slot(int d) { return (d - 3) / 2; }
 struct DeviceCtx {
     std::mutex mu;
     uint8_t* lut[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int* err = nullptr;             // error latch of the stateless entry points (tq_states_check)
     void* ws = nullptr;             // scratch of the stateless entry points
     size_t ws_bytes = 0;
     int num_cus = 0;
@@ -88,6 +89,10 @@ int get_lut(int dev, int d, hipStream_t stream, const uint8_t** out) {
         KCHECK();
         HIPCHECK(hipStreamSynchronize(stream));     // once per (device, d)
         c.lut[slot] = p;
+    }
+    if (!c.err) {
+        HIPCHECK(hipMalloc((void**)&c.err, sizeof(int)));
+        HIPCHECK(hipMemset(c.err, 0, sizeof(int)));
     }
     if (!c.num_cus) {
         hipDeviceProp_t prop;
@@ -388,7 +393,7 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
     const size_t w = (size_t)(d * d + 63) / 64;
     const size_t cnt_bytes = (((size_t)n * 4 + 32 + 15) & ~(size_t)15);
     const size_t part_bytes = (((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8;
-    const size_t need = 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes + 16;
+    const size_t need = 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes;
     if (c.ws_bytes < need) {
         if (c.ws) HIPCHECK(hipFree(c.ws));
         c.ws = nullptr; c.ws_bytes = 0;
@@ -399,7 +404,7 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
     *vp = (uint64_t*)c.ws;
     *counts = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8);
     *partial = (int64_t*)((char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes);
-    *err = (int*)((char*)c.ws + need - 16);
+    *err = c.err;
     return TQ_OK;
 }
 
@@ -409,6 +414,8 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
     if (n <= 0 || !states || !offsets) return fail(TQ_E_INVALID, "bad n / states / offsets");
     int dev;
     if (int rc = current_device(&dev)) return rc;
+    const uint8_t* lut_unused;
+    if (int rc = get_lut(dev, d, stream, &lut_unused)) return rc;
     uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
     if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
 #define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, cnt, (int64_t)n)
@@ -449,14 +456,28 @@ int tq_states_transition(int d, int n, const uint8_t* states, const uint8_t* nex
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut;
     if (int rc = get_lut(dev, d, stream, &lut)) return rc;
-    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
-    if (int rc = states_scratch(dev, d, 1, &vp, &cnt, &part, &err)) return rc;
+    int* err = g_ctx[dev].err;
     const int64_t total = (int64_t)n * 2 * d * d;
 #define CALL(D) hipLaunchKernelGGL(tq::k_states_transition<D>, grid1(total, 256), dim3(256), 0, stream, states, next_states, \
         actions, persp, next_persp, actions_out, lut, (int64_t)n, err)
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
+    return TQ_OK;
+}
+
+int tq_states_check(void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int dev;
+    if (int rc = current_device(&dev)) return rc;
+    int* latch = g_ctx[dev].err;
+    if (!latch) return TQ_OK;                                // no stateless call has run on this device yet
+    int flag = 0;
+    HIPCHECK(hipMemcpyAsync(&flag, latch, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    if (flag) HIPCHECK(hipMemsetAsync(latch, 0, sizeof(int), stream));
+    if (flag & tq::ERR_ACTION) return fail(TQ_E_ACTION, "an action outside the lattice or with op not in 1..3 was applied");
+    if (flag & tq::ERR_CAPACITY) return fail(TQ_E_CAPACITY, "perspective stack capacity exceeded");
     return TQ_OK;
 }
 

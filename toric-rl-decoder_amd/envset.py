@@ -465,6 +465,7 @@ def generateTransitionParallel(action, reward, state, next_state, terminal_state
     with torch.cuda.device(dev):
         check(L.tq_states_transition(d, n, _ptr(st), _ptr(nst), _ptr(act), _ptr(out["perspective"]),
                                      _ptr(out["next_perspective"]), _ptr(out["action"]), _stream()))
+        check(L.tq_states_check(_stream()))                       # bad action -> ValueError
     out["reward"] = np.asarray(reward, np.float64)
     out["terminal"] = np.asarray(terminal_state, bool)
     rec = to_structured(out, d)

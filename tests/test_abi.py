@@ -69,3 +69,22 @@ def test_python_surface_fails_loudly_without_gpu():
             T.EnvSet(env, 4)
     dt = T.transition_dtype(7)
     assert dt.itemsize == 1609                               # reference record at d=7
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: with libtoricenv.so absent, load() raises and nothing else is tried."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libtoricenv.so"))
+    with pytest.raises(T.ToricEnvError, match="no CPU fallback"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no module of the package may import it."""
+    import glob
+    pkg = os.path.join(ROOT, "toric-rl-decoder_amd")
+    for path in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True) + glob.glob(os.path.join(pkg, "csrc", "*")):
+        text = open(path, errors="ignore").read()
+        assert "import oracle" not in text and "from oracle" not in text and "toric_oracle" not in text, path

@@ -250,7 +250,7 @@ TQ_HD U4 draw(uint64_t seed, uint32_t env, uint32_t episode, uint32_t round, uin
 TQ_HD double u01(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
 
 // env.reset(p_error): depolarizing draw rounds until the syndrome is non-empty
-// (results/small_p_error_test.py:22-31,109-120).  RNG contract: oracle/toric_oracle.py.
+// (results/small_p_error_test.py:22-31,109-120).  RNG contract: DESIGN.md section 4.
 template <int D>
 TQ_HD int reset_lattice(typename Lat<D>::State& s, uint64_t seed, uint32_t env, uint32_t episode, double p) {
     using L = Lat<D>;

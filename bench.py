@@ -28,6 +28,7 @@ write kernel, HIP events around every launch in the timed region) and `cpu_basel
 oracle's actor loop on the host cores, rank 0, N=1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -60,6 +61,9 @@ def parse():
     ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture --flush steps in a HIP graph and replay it (launch-bound small batches; implies "
+                         "--no-events: no per-launch timing inside a graph, so no roofline object)")
     ap.add_argument("--policy", default="explore", choices=["explore", "nn11"],
                     help="explore: eps=1 selection in the fused kernel (default, the env path alone); "
                          "nn11: NN_11 forward on the stack + device eps-greedy selection in the loop (NN-bound)")
@@ -141,7 +145,12 @@ def main():
         sys.exit("--envs must be divisible by --shards")
     ns = n // S
     flush = max(1, args.flush)
-    use_events = not args.no_events
+    use_events = not args.no_events and not args.graph
+    if args.graph and (args.policy != "explore" or world > 1 or args.shards != 1):
+        sys.exit("--graph supports the single-GPU, single-stream explore policy only")
+    if args.graph:
+        K = max(flush, K - K % flush)                                  # whole replays
+        W = max(flush, W - W % flush)
 
     model = None
     if args.policy == "nn11":
@@ -178,7 +187,8 @@ def main():
 
     def one_step(k, t, timed_idx=None):
         sh = shards[k]
-        with torch.cuda.stream(sh.stream):
+        # one shard: stay on torch's current stream (inside torch.cuda.graph() that is the capture stream)
+        with (torch.cuda.stream(sh.stream) if S > 1 else contextlib.nullcontext()):
             envs, off = sh.envs, sh.offs[t]
             envs.perspectiveCounts(off)
             if S > 1:
@@ -212,14 +222,38 @@ def main():
             g.gather(shards[k].blocks[1].buf)
             g.wait()
     barrier()
-    for t in range(W):
-        for k in range(S):
-            one_step(k, t)
+    graph = None
+    if args.graph:
+        # the capture stream is torch's current stream inside torch.cuda.graph(); every ABI call
+        # enqueues on it, no call allocates or synchronises, so the whole flush window is capturable
+        sh0 = shards[0]
+        p_acc = torch.zeros(flush, dtype=torch.int64, device=device)
+        for t in range(flush):                                        # eager once (lazy init, LUT)
+            one_step(0, t)
+        torch.cuda.synchronize(device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for t in range(flush):
+                one_step(0, t)
+                p_acc[t:t + 1].add_(sh0.offs[t, -1:])                 # running sum of P per slot of the window
+        p_acc.zero_()
+
+    def run_steps(first, count, timed):
+        if graph is not None:
+            for _ in range(count // flush):
+                graph.replay()
+            return
+        for i in range(count):
+            for k in range(S):
+                one_step(k, first + i, i if timed else None)
+
+    run_steps(0, W, False)
     barrier()
+    if graph is not None:
+        p_acc.zero_()
+        torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for i in range(K):
-        for k in range(S):
-            one_step(k, W + i, i)
+    run_steps(W, K, True)
     if tg is not None:
         for k, g in enumerate(tg):
             with torch.cuda.stream(shards[k].stream):
@@ -233,7 +267,10 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    p_timed = torch.stack([sh.offs[W:, -1] for sh in shards]).to(torch.float64)       # (S, K) perspectives per launch
+    if graph is not None:      # slot t of the captured window accumulated its P over the K/flush replays
+        p_timed = (p_acc.to(torch.float64) / (K // flush)).repeat(K // flush).reshape(1, -1)
+    else:
+        p_timed = torch.stack([sh.offs[W:, -1] for sh in shards]).to(torch.float64)   # (S, K) perspectives per launch
     p_sum = p_timed.sum().reshape(1).to(red_dev)
     if world > 1:
         dist.all_reduce(p_sum, op=dist.ReduceOp.SUM)
@@ -253,7 +290,7 @@ def main():
                                    (n, d, args.p_error, args.out_dtype, policy_txt),
                        "policy": args.policy, "envs_per_gpu": n, "d": d, "p_error": args.p_error,
                        "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
-                       "streams_per_gpu": S, "parallelism": "env-shard x%d" % world,
+                       "streams_per_gpu": S, "hip_graph": bool(args.graph), "parallelism": "env-shard x%d" % world,
                        "collective": None if world == 1 else
                        "transition gather to rank 0 (%s) every %d steps" % (backend, flush)},
             "perspectives_per_sec": float(p_sum.item()) / elapsed,

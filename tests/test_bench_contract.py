@@ -38,3 +38,15 @@ def test_bench_json_contract():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert j["value"] > 1e6 and abs(j["value"] - 8192 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_graph_mode():
+    """--graph: the flush window captured into a HIP graph (every ABI call is capture-safe: no allocation,
+    no synchronisation, caller's stream) and replayed; same JSON contract minus the per-launch roofline."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "32", "--warmup", "8", "--envs", "2048",
+                        "--cpu-seconds", "0", "--graph"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert j["config"]["hip_graph"] is True and "roofline" not in j
+    assert j["steps"] == 32 and j["value"] > 1e6 and j["perspectives_per_sec"] > 30 * j["value"]

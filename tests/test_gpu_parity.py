@@ -436,3 +436,31 @@ def test_full_size_configs(T, d, p, n):
     got = per[torch.as_tensor(rows, device=per.device)].cpu().numpy()
     assert np.array_equal(got, bp.astype(np.float32))
     gpu.close()
+
+
+@pytest.mark.parametrize("d,n,steps", [(3, 3000, 400), (5, 4096, 300), (7, 2048, 200), (9, 1024, 160)])
+def test_long_run_matches_c_oracle_actor_loop(T, d, n, steps):
+    """Soak: hundreds of fused exploration steps (selection, step, auto-reset at 75 steps or when solved;
+    d=3 needs several redraw rounds per reset) against the C oracle's actor loop; the whole lattice state
+    and every counter must match at the end, and the perspective totals along the way."""
+    from oracle.c_oracle import CEnvBatch
+    p = P_OF[d]
+    env = T.make("toric-code-v0", {"size": d, "p_error": p})
+    gpu = T.EnvSet(env, n, seed=606, first_env_id=17, numpy_io=False)
+    ce = CEnvBatch(d, n, p, seed=606, first_env_id=17)
+    gpu.resetAll()
+    ce.reset()
+    p_gpu = torch.zeros((), dtype=torch.int64, device=gpu.device)
+    for t in range(steps):
+        cnt, off = gpu.perspectiveCounts()
+        p_gpu += off[-1]
+        gpu.actorStep(None, want_actions=False)
+    P, _ = ce.actor_steps(steps)
+    assert int(p_gpu.item()) == P
+    assert np.array_equal(gpu.getQubits().cpu().numpy(), ce.qubits)
+    assert np.array_equal(gpu.getStates().cpu().numpy(), ce.states)
+    ep, st = gpu.getCounters()
+    assert np.array_equal(ep.cpu().numpy().astype(np.uint32), ce.episodes) and np.array_equal(st.cpu().numpy().astype(np.uint32), ce.steps)
+    assert ce.episodes.min() >= 2 and ce.episodes.max() >= 3          # every lattice was reset at least once
+    gpu.check()
+    gpu.close()

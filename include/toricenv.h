@@ -18,7 +18,13 @@
  *    qubit codes I=0 X=1 Y=2 Z=3 (docs/toric_model.md:11); action = [layer,row,col,op],
  *    op in 1..3 (src/util.py:10, src/numba/util_actor.py:100-104).
  *  - a handle is not thread-safe; use one handle per process / GPU
- *    (one actor process per device: Distributed_mp.py:201-211).
+ *    (one actor process per device: Distributed_mp.py:201-211).  Entry points make the handle's
+ *    device current while they run and restore the caller's device before returning.
+ *  - set-up calls (tq_create, tq_destroy, tq_set_perror_schedule, the first use of a lattice size on
+ *    a device) allocate and synchronise; everything else only enqueues kernels.
+ *  - the tq_states_* entry points and tq_transition_write share one per-device scratch area that
+ *    grows on demand: calls that use it must be issued on one stream (or be separated by a
+ *    synchronisation) -- they are stream-ordered, not re-entrant across streams.
  *  - RNG: counter-based Philox4x32-10 keyed (seed, global env id, episode, round/step);
  *    contract in DESIGN.md.  Results are identical for any partition of env ids over GPUs.
  */

@@ -165,15 +165,26 @@ struct tq_env {
 };
 
 namespace {
-int check_handle(const tq_env* h) {
-    if (!h) return fail(TQ_E_INVALID, "NULL handle");
-    int dev;
-    if (int rc = current_device(&dev)) return rc;
-    if (dev != h->device) HIPCHECK(hipSetDevice(h->device));
-    return TQ_OK;
-}
+// Makes the handle's device current for the duration of one entry point and restores the caller's
+// device on the way out (PyTorch callers already run under torch.cuda.device(...); C callers must
+// not find their current device changed behind their back).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(const tq_env* h) {
+        if (!h) return fail(TQ_E_INVALID, "NULL handle");
+        if (int rc = current_device(&prev)) return rc;
+        if (prev != h->device) {
+            HIPCHECK(hipSetDevice(h->device));
+            switched = true;
+        }
+        return TQ_OK;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 #define HANDLE(h)                                  \
-    if (int _rc = check_handle(h)) return _rc;     \
+    DeviceGuard _guard;                            \
+    if (int _rc = _guard.enter(h)) return _rc;     \
     hipStream_t stream = (hipStream_t)stream_
 }  // namespace
 
@@ -239,7 +250,8 @@ int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int
 }
 
 int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_final, double p_delta) {
-    if (int rc = check_handle(h)) return rc;
+    DeviceGuard guard;
+    if (int rc = guard.enter(h)) return rc;
     if (strategy < TQ_PERR_FIXED || strategy > TQ_PERR_RANDOM) return fail(TQ_E_INVALID, "unknown p_error strategy %d", strategy);
     h->sched.strategy = strategy; h->sched.p_start = p_start; h->sched.p_final = p_final; h->sched.p_delta = p_delta;
     // env_p_errors = ones * p_start (Actor_mp.py:46)

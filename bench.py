@@ -309,8 +309,18 @@ def main():
                         traffic = j.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+            # context: the box's own streaming-fill bandwidth, measured after the timed region
+            # on the same buffer (hipMemsetAsync through torch), so frac can be read against it as well
+            fb = shards[0].stack.view(torch.uint8).reshape(-1)[:int(alg) & ~4095]
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fill_ms = []
+            for _ in range(6):
+                f0.record(); fb.zero_(); f1.record(); f1.synchronize()
+                fill_ms.append(f0.elapsed_time(f1))
+            fill_gbps = fb.numel() / (min(fill_ms[1:]) * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "kernel": "k_persp_write", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                               "measured_fill_gbps": fill_gbps, "frac_of_measured_fill": achieved / fill_gbps,
                                "bytes_per_launch": alg, "avg_launch_ms": float(ms.mean()),
                                "median_launch_ms": float(np.median(ms)), "perspectives_per_launch": p_mean,
                                "launches_per_step": S, "lattices_per_launch": ns}

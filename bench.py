@@ -129,7 +129,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     red_dev = device if backend == "nccl" else torch.device("cpu")      # where scalar reductions live
-    if world > 1:
+    # TORIC_FORCE_DIST=1: run the collective path even with one rank (exercises the RCCL calls on a one-GPU box)
+    dist_on = world > 1 or os.environ.get("TORIC_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -182,7 +184,7 @@ def main():
     torch.cuda.synchronize(device)
     have_blocks = shards[0].blocks is not None
     tg = None
-    if world > 1 and have_blocks:
+    if dist_on and have_blocks:
         tg = [G.TransitionGather(sh.blocks[0].nbytes, device, ring_slots=2) for sh in shards]
 
     def one_step(k, t, timed_idx=None):
@@ -213,7 +215,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -264,7 +266,7 @@ def main():
         sh.envs.check()                                               # capacity / action latch
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     if graph is not None:      # slot t of the captured window accumulated its P over the K/flush replays
@@ -272,7 +274,7 @@ def main():
     else:
         p_timed = torch.stack([sh.offs[W:, -1] for sh in shards]).to(torch.float64)   # (S, K) perspectives per launch
     p_sum = p_timed.sum().reshape(1).to(red_dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(p_sum, op=dist.ReduceOp.SUM)
     total_steps = float(n) * world * K
 
@@ -291,7 +293,7 @@ def main():
                        "policy": args.policy, "envs_per_gpu": n, "d": d, "p_error": args.p_error,
                        "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
                        "streams_per_gpu": S, "hip_graph": bool(args.graph), "parallelism": "env-shard x%d" % world,
-                       "collective": None if world == 1 else
+                       "collective": None if not dist_on else
                        "transition gather to rank 0 (%s) every %d steps" % (backend, flush)},
             "perspectives_per_sec": float(p_sum.item()) / elapsed,
         }
@@ -329,7 +331,7 @@ def main():
         print(json.dumps(res), flush=True)
     for sh in shards:
         sh.envs.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--flush", type=int, default=8, help="steps per transition block / gather (N>1)")
     ap.add_argument("--shards", type=int, default=1, help="independent sub-shards (HIP streams) per GPU")
     ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
+    ap.add_argument("--host-drain", action="store_true",
+                    help="N>1: rank 0 also copies every gathered block to a pinned host ring (replay process side)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
     ap.add_argument("--graph", action="store_true",
@@ -185,7 +187,7 @@ def main():
     have_blocks = shards[0].blocks is not None
     tg = None
     if dist_on and have_blocks:
-        tg = [G.TransitionGather(sh.blocks[0].nbytes, device, ring_slots=2) for sh in shards]
+        tg = [G.TransitionGather(sh.blocks[0].nbytes, device, ring_slots=2, host_drain=args.host_drain) for sh in shards]
 
     def one_step(k, t, timed_idx=None):
         sh = shards[k]
@@ -294,7 +296,7 @@ def main():
                        "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
                        "streams_per_gpu": S, "hip_graph": bool(args.graph), "parallelism": "env-shard x%d" % world,
                        "collective": None if not dist_on else
-                       "transition gather to rank 0 (%s) every %d steps" % (backend, flush)},
+                       "transition gather to rank 0 (%s) every %d steps%s" % (backend, flush, " + D2H drain to pinned host ring" if args.host_drain else "")},
             "perspectives_per_sec": float(p_sum.item()) / elapsed,
         }
         if use_events:

@@ -155,3 +155,40 @@ def test_actor_loop_matches_oracle_loop(T):
             assert np.array_equal(u["reward"].cpu().numpy(), rew)
         assert np.array_equal(gpu.getStates().cpu().numpy(), ora.states)
     gpu.close()
+
+
+def test_transition_gather_rccl_single_rank_with_host_drain(T):
+    """The RCCL path of TransitionGather (world of one rank on this box) incl. the asynchronous drain
+    of every gathered slot to the pinned host ring; bytes must arrive unchanged and decode."""
+    import os
+    import torch.distributed as dist
+    from toric_rl_decoder_amd import gather, wire
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        d, n = 7, 512
+        env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+        gpu = T.EnvSet(env, n, seed=77, numpy_io=False)
+        gpu.resetAll()
+        blocks = [gpu.newTransitionBlock(steps=2) for _ in range(2)]
+        tg = gather.TransitionGather(blocks[0].nbytes, dev, ring_slots=2, host_drain=True)
+        sent = []
+        for f in range(5):                                    # 5 flushes through a 2-slot ring
+            blk = blocks[f & 1]
+            for t in range(2):
+                gpu.perspectiveCounts()
+                gpu.actorStep(None, block=blk, slot=t)
+            slot = tg.gather(blk.buf)
+            torch.cuda.synchronize()
+            sent.append((slot, blk.buf.clone()))
+        tg.wait()
+        for slot, want in sent[-2:]:                          # the two newest flushes are still in the ring
+            assert torch.equal(tg.slot_view(slot, 0), want)
+            assert torch.equal(tg.slot_view(slot, 0, host=True), want.cpu())
+        rec = wire.decode(tg.slot_view(sent[-1][0], 0, host=True).numpy(), d, 2 * n)
+        assert rec["perspective"].shape == (2 * n, 2, d, d) and set(np.unique(rec["action"][:, 3])) <= {1, 2, 3}
+        gpu.close()
+    finally:
+        dist.destroy_process_group()

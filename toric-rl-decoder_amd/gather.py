@@ -29,7 +29,7 @@ class TransitionGather:
     ``wait()`` blocks until every outstanding exchange has completed.
     """
 
-    def __init__(self, block_nbytes, device, ring_slots=2, group=None):
+    def __init__(self, block_nbytes, device, ring_slots=2, group=None, host_drain=False):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -42,6 +42,16 @@ class TransitionGather:
         if self.rank == 0:
             self.ring = torch.zeros((self.ring_slots, self.world, self.nbytes), dtype=torch.uint8,
                                     device=self.stage_device)
+        # optional drain to the host replay process: every gathered slot is copied to a pinned host
+        # ring on a dedicated copy stream (D2H overlaps the env kernels; a slot is only re-used once
+        # its copy has finished, so PCIe back-pressures the actors only if it cannot keep up)
+        self.host_ring = None
+        self._copy_stream = None
+        self._drained = []
+        if host_drain and self.rank == 0 and self.stage_device.type == "cuda":
+            self.host_ring = torch.empty((self.ring_slots, self.world, self.nbytes), dtype=torch.uint8).pin_memory()
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._drained = [torch.cuda.Event() for _ in range(self.ring_slots)]
         self._next = 0
         self._pending = []
 
@@ -52,8 +62,15 @@ class TransitionGather:
         self._next += 1
         src = buf if buf.device == self.stage_device else buf.to(self.stage_device)
         outs = [self.ring[slot, r] for r in range(self.world)] if self.rank == 0 else None
+        if self.host_ring is not None and self._next > self.ring_slots:
+            torch.cuda.current_stream(self.device).wait_event(self._drained[slot])   # slot still being copied out?
         work = dist.gather(src, gather_list=outs, dst=0, group=self.group, async_op=True)
         self._pending.append((work, src))
+        if self.host_ring is not None:
+            with torch.cuda.stream(self._copy_stream):
+                work.wait()                                     # copy stream waits for the collective, not the host
+                self.host_ring[slot].copy_(self.ring[slot], non_blocking=True)
+                self._drained[slot].record(self._copy_stream)
         if len(self._pending) >= self.ring_slots:          # never overwrite a slot still in flight
             self._drain(1)
         return slot
@@ -65,9 +82,12 @@ class TransitionGather:
 
     def wait(self):
         self._drain(0)
+        if self._copy_stream is not None:
+            self._copy_stream.synchronize()
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
 
-    def slot_view(self, slot, rank):
-        """Root only: the bytes rank `rank` contributed to ring slot `slot`."""
-        return self.ring[slot, rank]
+    def slot_view(self, slot, rank, host=False):
+        """Root only: the bytes rank `rank` contributed to ring slot `slot` (device ring, or the pinned
+        host copy when the gather was created with host_drain=True)."""
+        return (self.host_ring if host else self.ring)[slot, rank]

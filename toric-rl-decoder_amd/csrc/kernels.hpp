@@ -605,55 +605,37 @@ __global__ void k_build_lut(uint8_t* __restrict__ lut) {
 //     trailing elements belong to the following lattice(s) and are resolved from their bit-planes.
 // The leading elements of a segment that sit in a line begun by an earlier lattice are written by
 // that lattice's wave, by the same rule.
-template <int D, typename OutT, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restrict__ vp, int64_t N,
-                                                         const int64_t* __restrict__ offsets, OutT* __restrict__ out,
-                                                         int32_t* __restrict__ pos, int64_t capacity,
-                                                         const uint8_t* __restrict__ lut_g, int* __restrict__ err) {
+// Everything one wavefront does for one lattice of the stack (see the ownership rule above).
+// lut / hw / cw: the workgroup's LUT and this wave's LDS tables; all 64 lanes call it with the same e.
+template <int D, typename OutT>
+__device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restrict__ vp, int64_t N,
+                                              const int64_t* __restrict__ offsets, OutT* __restrict__ out,
+                                              int32_t* __restrict__ pos, int64_t capacity, const uint8_t* __restrict__ lut,
+                                              uint16_t* __restrict__ hw, uint8_t* __restrict__ cw, int* __restrict__ err,
+                                              int lane) {
     using L = Lat<D>;
     using Enc = OutEnc<OutT>;
     constexpr int DD = L::DD, NQ = L::NQ, W = L::W;
-    constexpr int WAVES = THREADS / 64;
     constexpr int VEC = 16 / (int)sizeof(OutT);              // elements per 16-byte lane store
     constexpr int EPW = 32 / Enc::BITS;                      // elements per dword
     constexpr int LE = 128 / (int)sizeof(OutT);              // elements per 128-byte line
-    constexpr int LUT_BYTES = (NQ * NQ + 15) & ~15;
-    constexpr int NQP = (NQ + 3) & ~3;
-    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
-    __shared__ uint8_t cellv[WAVES][NQP];                    // syndrome cells (0/1) of the wave's lattice
-    __shared__ uint16_t hits[WAVES][NQP];                    // k-th hit -> flat qubit index * NQ (its LUT row offset)
-
-    // the wave index is made provably uniform so that the lattice id, its plane words and its
-    // offset live in SGPRs (scalar loads) and the hit masks are computed on the scalar unit
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t e = (int64_t)blockIdx.x * WAVES + wave;
-    const bool live = e < N;
     typename L::B v, p, e0, e1;
-    int n0 = 0, n = 0;
-    int64_t off = 0;
-    if (live) {
 #pragma unroll
-        for (int k = 0; k < W; ++k) { v.w[k] = vp[(int64_t)k * N + e]; p.w[k] = vp[((int64_t)W + k) * N + e]; }
-        L::hit_masks(v, p, e0, e1);
-        n0 = e0.popc();
-        n = n0 + e1.popc();
-        off = offsets[e];
-    }
-    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
-        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
-    if (live && n > 0) {
-        for (int c = lane; c < NQ; c += 64) {
-            const int l = c >= DD, bit = c - l * DD;
-            cellv[wave][c] = (uint8_t)(l ? p.get(bit) : v.get(bit));
-            const int is_hit = l ? e1.get(bit) : e0.get(bit);
-            if (is_hit) hits[wave][l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint16_t)(c * NQ);
-        }
-    }
-    __syncthreads();
-    if (!live || n == 0) return;
+    for (int k = 0; k < W; ++k) { v.w[k] = vp[(int64_t)k * N + e]; p.w[k] = vp[((int64_t)W + k) * N + e]; }
+    L::hit_masks(v, p, e0, e1);
+    const int n0 = e0.popc();
+    const int n = n0 + e1.popc();
+    if (n == 0) return;
+    const int64_t off = offsets[e];
     if (off + n > capacity) { if (lane == 0) atomicOr(err, ERR_CAPACITY); return; }
-    const uint16_t* __restrict__ hw = hits[wave];
-    const uint8_t* __restrict__ cw = cellv[wave];
+    for (int c = lane; c < NQ; c += 64) {
+        const int l = c >= DD, bit = c - l * DD;
+        cw[c] = (uint8_t)(l ? p.get(bit) : v.get(bit));
+        const int is_hit = l ? e1.get(bit) : e0.get(bit);
+        if (is_hit) hw[l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint16_t)(c * NQ);
+    }
+    wave_lds_sync();
+
 
     // positions (P,3) i32: (layer,row,col) of each hit.  Same ownership rule on its own 128-byte
     // lines (32 dwords): whole lines inside the lattice's [plo, phi) by 16-byte stores here, the
@@ -804,6 +786,70 @@ __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restr
         }
     }
     if (p_lane && y < p_limit) pos[y] = pval;
+}
+
+template <int D, typename OutT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restrict__ vp, int64_t N,
+                                                         const int64_t* __restrict__ offsets, OutT* __restrict__ out,
+                                                         int32_t* __restrict__ pos, int64_t capacity,
+                                                         const uint8_t* __restrict__ lut_g, int* __restrict__ err) {
+    constexpr int NQ = Lat<D>::NQ;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int LUT_BYTES = (NQ * NQ + 15) & ~15;
+    constexpr int NQP = (NQ + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
+    __shared__ uint8_t cellv[WAVES][NQP];                    // syndrome cells (0/1) of the wave's lattice
+    __shared__ uint16_t hits[WAVES][NQP];                    // k-th hit -> flat qubit index * NQ (its LUT row offset)
+    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
+        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
+    __syncthreads();
+    // the wave index is made provably uniform so that the lattice id, its plane words and its
+    // offset live in SGPRs (scalar loads) and the hit masks are computed on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * WAVES + wave;
+    if (e < N) persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, lut, hits[wave], cellv[wave], err, lane);
+}
+
+// Persistent variant: the workgroups stay resident (the LUT is fetched once per workgroup instead of
+// once per 4 lattices, no 16 k workgroup launches) and every wave draws its lattices from one of 8
+// ticket counters (shard = blockIdx & 7).  The next ticket is requested BEFORE the current lattice is
+// written: loads/atomics and stores share the in-order vmcnt counter, so its return only waits for
+// operations older than itself (the previous lattice's stores, long retired) and never drains the
+// store queue.  Lattice of ticket t in shard s: t * 8 + s.
+template <int D, typename OutT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_persp_write_dyn(const uint64_t* __restrict__ vp, int64_t N,
+                                                             const int64_t* __restrict__ offsets, OutT* __restrict__ out,
+                                                             int32_t* __restrict__ pos, int64_t capacity,
+                                                             const uint8_t* __restrict__ lut_g, int* __restrict__ err,
+                                                             unsigned long long* __restrict__ tickets) {
+    constexpr int NQ = Lat<D>::NQ;
+    constexpr int WAVES = THREADS / 64;
+    constexpr int LUT_BYTES = (NQ * NQ + 15) & ~15;
+    constexpr int NQP = (NQ + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
+    __shared__ uint8_t cellv[WAVES][NQP];
+    __shared__ uint16_t hits[WAVES][NQP];
+    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
+        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int shard = blockIdx.x & 7;
+    unsigned long long* ctr = tickets + shard * 16;          // one counter per 128-byte line
+    auto draw_ticket = [&]() -> long long {
+        unsigned long long t = 0;
+        if (lane == 0) t = atomicAdd(ctr, 1ull);
+        return (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)t));
+    };
+    long long cur = draw_ticket();
+    for (;;) {
+        const int64_t e = cur * 8 + shard;
+        if (e >= N) break;
+        const long long nxt = draw_ticket();                  // in flight while this lattice is written
+        persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, lut, hits[wave], cellv[wave], err, lane);
+        wave_lds_sync();
+        cur = nxt;
+    }
 }
 
 // generateTransitionParallel on explicit u8 grids: one thread per output byte, the (hit, cell)

@@ -810,48 +810,6 @@ __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restr
     if (e < N) persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, lut, hits[wave], cellv[wave], err, lane);
 }
 
-// Persistent variant: the workgroups stay resident (the LUT is fetched once per workgroup instead of
-// once per 4 lattices, no 16 k workgroup launches) and every wave draws its lattices from one of 8
-// ticket counters (shard = blockIdx & 7).  The next ticket is requested BEFORE the current lattice is
-// written: loads/atomics and stores share the in-order vmcnt counter, so its return only waits for
-// operations older than itself (the previous lattice's stores, long retired) and never drains the
-// store queue.  Lattice of ticket t in shard s: t * 8 + s.
-template <int D, typename OutT, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_persp_write_dyn(const uint64_t* __restrict__ vp, int64_t N,
-                                                             const int64_t* __restrict__ offsets, OutT* __restrict__ out,
-                                                             int32_t* __restrict__ pos, int64_t capacity,
-                                                             const uint8_t* __restrict__ lut_g, int* __restrict__ err,
-                                                             unsigned long long* __restrict__ tickets) {
-    constexpr int NQ = Lat<D>::NQ;
-    constexpr int WAVES = THREADS / 64;
-    constexpr int LUT_BYTES = (NQ * NQ + 15) & ~15;
-    constexpr int NQP = (NQ + 3) & ~3;
-    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
-    __shared__ uint8_t cellv[WAVES][NQP];
-    __shared__ uint16_t hits[WAVES][NQP];
-    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
-        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int shard = blockIdx.x & 7;
-    unsigned long long* ctr = tickets + shard * 16;          // one counter per 128-byte line
-    auto draw_ticket = [&]() -> long long {
-        unsigned long long t = 0;
-        if (lane == 0) t = atomicAdd(ctr, 1ull);
-        return (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
-                           (unsigned)__builtin_amdgcn_readfirstlane((int)t));
-    };
-    long long cur = draw_ticket();
-    for (;;) {
-        const int64_t e = cur * 8 + shard;
-        if (e >= N) break;
-        const long long nxt = draw_ticket();                  // in flight while this lattice is written
-        persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, lut, hits[wave], cellv[wave], err, lane);
-        wave_lds_sync();
-        cur = nxt;
-    }
-}
-
 // generateTransitionParallel on explicit u8 grids: one thread per output byte, the (hit, cell)
 // -> source-cell table does shift_state + rotate_state in one lookup; loads and stores coalesced.
 template <int D>

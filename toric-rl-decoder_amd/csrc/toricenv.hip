@@ -117,23 +117,12 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
 
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
-                         int64_t capacity, const uint8_t* lut, int* err, unsigned long long* tickets, int num_cus,
-                         hipStream_t stream) {
+                         int64_t capacity, const uint8_t* lut, int* err, hipStream_t stream) {
     constexpr int THREADS = D <= 7 ? 256 : (D == 9 ? 512 : 1024);
     constexpr int WAVES = THREADS / 64;
-    // TQ_WRITE_DYN=1: persistent workgroups drawing lattices from ticket counters (A/B experiment);
-    // default: one lattice per wave, the hardware dispatcher balances the variable-size lattices.
-    static const int dyn = getenv("TQ_WRITE_DYN") ? atoi(getenv("TQ_WRITE_DYN")) : 0;
-    if (dyn && tickets) {
-        HIPCHECK(hipMemsetAsync(tickets, 0, 8 * 16 * sizeof(unsigned long long), stream));
-        const int64_t want = (n + WAVES - 1) / WAVES;
-        const int64_t resident = (int64_t)num_cus * (2048 / THREADS) * (dyn > 1 ? 1 : 1);
-        const int64_t blocks = want < resident ? want : resident;
-        hipLaunchKernelGGL((tq::k_persp_write_dyn<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
-                           offsets, (OutT*)out, pos, capacity, lut, err, tickets);
-        KCHECK();
-        return TQ_OK;
-    }
+    // One lattice per wave; the hardware dispatcher balances the variable-size lattices.  Persistent
+    // waves (static, or drawing tickets), fixed aligned windows and cooperative workgroups were all
+    // built or prototyped and are slower or equal in the real kernel (git history).
     const int64_t blocks = (n + WAVES - 1) / WAVES;
     hipLaunchKernelGGL((tq::k_persp_write<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
                        offsets, (OutT*)out, pos, capacity, lut, err);
@@ -143,13 +132,12 @@ int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, 
 
 template <int D>
 int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
-                       int64_t capacity, int dtype, const uint8_t* lut, int* err, unsigned long long* tickets, int num_cus,
-                       hipStream_t stream) {
+                       int64_t capacity, int dtype, const uint8_t* lut, int* err, hipStream_t stream) {
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, lut, err, tickets, num_cus, stream);
-        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, lut, err, tickets, num_cus, stream);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, lut, err, tickets, num_cus, stream);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, lut, err, tickets, num_cus, stream);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, lut, err, stream);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, lut, err, stream);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, lut, err, stream);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, lut, err, stream);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -170,7 +158,6 @@ struct tq_env {
     int32_t* counts;
     int64_t* partial;      // level-1 sums of the scan: one per 256 counts
     bool partial_valid;    // left current by the last all-lattice kernel (false after tq_reset_idx)
-    unsigned long long* tickets;   // 8 ticket counters (one per 128-byte line) of the persistent stack write
     double* p_roof;
     int* err;              // device error latch
     const uint8_t* lut;
@@ -235,7 +222,6 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc((void**)&h->counts, N * 4 + 32);                      // +32: int4 tail loads of the scan stay in bounds
     alloc((void**)&h->partial, ((N + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8);
     alloc((void**)&h->p_roof, N * 8);
-    alloc((void**)&h->tickets, 8 * 16 * sizeof(unsigned long long));
     alloc((void**)&h->err, 4);
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
@@ -248,7 +234,7 @@ int tq_destroy(tq_env* h) {
     if (!h) return TQ_OK;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->planes); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
-    (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->tickets); (void)hipFree(h->err);
+    (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->err);
     delete h;
     return TQ_OK;
 }
@@ -406,7 +392,7 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
     if (!offsets || !out) return fail(TQ_E_INVALID, "offsets / out is NULL");
     if (capacity < 0) return fail(TQ_E_INVALID, "negative capacity");
     const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->lut, h->err, h->tickets, h->num_cus, stream)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->lut, h->err, stream)) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;
@@ -467,7 +453,7 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, lut, err, (unsigned long long*)nullptr, g_ctx[dev].num_cus, stream)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, lut, err, stream)) return rc
     DISPATCH_D(d, CALL)
 #undef CALL
     return TQ_OK;

@@ -2,107 +2,164 @@
 """Headline benchmark of the toric-code env hot path on MI355X.
 
 A "step" is one pass of the hot path over one batch of lattices, in the call order of the
-reference's actor loop (src/Actor_mp.py:104-185) with the policy network left out (it is stock
-torch conv work, out of scope; epsilon starts at 1 upstream, Actor_mp.py:37, where the Q-values
-never influence the action):
+reference's actor loop (src/Actor_mp.py:104-185) with the policy network left out of the headline
+(it is stock torch conv work, out of scope; epsilon starts at 1 upstream, Actor_mp.py:37, where the
+Q-values never influence the action):
 
     perspective counts -> exclusive scan -> perspective stack write (P,2,d,d) f32 + positions
     -> eps=1 selection, env step, transition record, auto-reset, next counts (one fused kernel)
+    -> every --flush steps: priorities into the packed block (computePrioritiesParallel with Q = 0)
 
-Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on:
-65 536 lattices, d=7, p_error=0.10.  Inputs are resident in HBM when the timed region starts
-(the lattices live on the device; nothing crosses PCIe in the loop).
+Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on: 65 536
+lattices, d=7, p_error=0.10.  Lattices are resident in HBM when the timed region starts; nothing
+crosses PCIe in the N=1 loop.  Before the warm-up the episodes are staggered (burn-in: lattice e is
+reset at step e mod 76), so the population -- and with it perspectives per lattice -- is stationary
+and `value` does not depend on --steps.
 
-Optional (--shards S > 1, default 1): lattices are independent, so the batch can be processed as S
-sub-shards on separate HIP streams, one shard's latency-bound kernels (scan, fused step) running
-beside another's stack write; writes are ordered against each other with events so their HIP-event
-timing stays clean.  Measured slower than one stream, hence off by default.
+N>1: `python bench.py --gpus N` starts N ranks by itself (a `python -m torch.distributed.run` child,
+before this process touches the GPU) and relays rank 0's JSON line; under torch.distributed.run
+(WORLD_SIZE set) it runs as a rank.  One rank per GPU; every rank owns a contiguous block of global
+env ids (weak scaling).  Default shape for N>1: BASELINE.json configs[4] -- 131 072 lattices per
+GPU, and every transition (with its priority) is delivered to the HOST replay ring: RCCL gather of
+the packed blocks to rank 0 over xGMI every --flush steps, then rank 0's copy stream drains each
+gathered slot to pinned host memory.  The rate with the ring kept in rank 0's HBM is measured right
+after and reported beside it (`hbm_ring`).
 
-N>1 (launched by torch.distributed.run, one rank per GPU): every rank owns a contiguous block of
-global env ids (weak scaling: 65 536 lattices per GPU); the only exchange is the gather of packed
-transition blocks to rank 0's HBM replay ring (RCCL over xGMI) every --flush steps, issued async
-so it overlaps the next steps.
-
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (perspective
-write kernel, HIP events around every launch in the timed region) and `cpu_baseline` (the C
-oracle's actor loop on the host cores, rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (perspective write
+kernel, HIP events around every launch in the timed region), `cpu_baseline` (the C oracle's actor
+loop on the host cores, rank 0, N=1 only) and `nn_in_loop` (configs[2] as written: the stack fed
+to NN_11 and device-side selection in the loop; N=1 only, --nn-steps 0 to skip).
 """
 import argparse
 import contextlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes), before HIP initialises
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
+EPISODE = 76                    # a lattice is auto-reset once its step counter exceeds 75 (Distributed_mp.py:44)
+ENVS_N1, ENVS_MULTI = 65536, 131072     # BASELINE configs[2] / configs[4] lattices per GPU
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=65536, help="lattices per GPU")
+    ap.add_argument("--envs", type=int, default=None,
+                    help="lattices per GPU (default: 65536 at N=1 = configs[2]; 131072 at N>1 = configs[4])")
     ap.add_argument("--size", type=int, default=7)
     ap.add_argument("--p-error", type=float, default=0.10)
     ap.add_argument("--seed", type=int, default=2020)
     ap.add_argument("--out-dtype", default="f32", choices=["f32", "f16", "bf16", "u8"])
-    ap.add_argument("--flush", type=int, default=8, help="steps per transition block / gather (N>1)")
+    ap.add_argument("--flush", type=int, default=8, help="steps per transition block / priorities / gather")
     ap.add_argument("--shards", type=int, default=1, help="independent sub-shards (HIP streams) per GPU")
     ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
-    ap.add_argument("--host-drain", action="store_true",
-                    help="N>1: rank 0 also copies every gathered block to a pinned host ring (replay process side)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--delivery", default="auto", choices=["auto", "host", "hbm"],
+                    help="N>1: where gathered transition blocks end up. host = pinned host replay ring (default for "
+                         "N>1, north_star), hbm = ring in rank 0's HBM only")
+    ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--nn-steps", type=int, default=2,
+                    help="N=1: timed steps of the NN_11-in-the-loop leg (configs[2] as written); 0 = skip")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
     ap.add_argument("--graph", action="store_true",
                     help="capture --flush steps in a HIP graph and replay it (launch-bound small batches; implies "
                          "--no-events: no per-launch timing inside a graph, so no roofline object)")
     ap.add_argument("--policy", default="explore", choices=["explore", "nn11"],
                     help="explore: eps=1 selection in the fused kernel (default, the env path alone); "
-                         "nn11: NN_11 forward on the stack + device eps-greedy selection in the loop (NN-bound)")
+                         "nn11: NN_11 forward on the stack + device eps-greedy selection in the main loop (NN-bound)")
     ap.add_argument("--eps", type=float, default=0.1, help="epsilon of the nn11 policy")
-    ap.add_argument("--nn-dtype", default="bf16", choices=["f32", "bf16"], help="autocast dtype of the nn11 forward")
-    return ap.parse_args()
+    ap.add_argument("--nn-dtype", default="f32", choices=["f32", "bf16"], help="dtype of the NN_11 forward (f32 upstream)")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------- self-launch (N > 1)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torch.distributed.run around it: start the N ranks as a CHILD
+    process tree and relay rank 0's JSON line.  This parent never initialises the GPU (no torch.cuda
+    call, not even torch is imported here) and never re-execs itself."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if p.returncode != 0:
+        sys.exit(p.returncode)
+    if line is None:
+        sys.exit("bench.py: the ranks exited cleanly but rank 0 printed no result line")
+
+
+# ---------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(d, p, seed, budget_s):
     """The oracle's C actor loop (EnvSet.step + generatePerspectiveBatch + generateTransitionParallel
-    restated, oracle/toric_oracle.c) timed on the host cores: bounded sample of the same workload."""
+    restated, oracle/toric_oracle.c) timed on the host cores: bounded sample of the same workload, on
+    all cores this process may use (`value`) and on one core; plus the same loop in the reference's
+    own shape (per-lattice python + np.roll, int64, fresh allocations) on 256 lattices x 20 steps
+    (SURVEY 8d), one process like the reference's actor."""
     from oracle.c_oracle import CEnvBatch, lib
     L = lib()
     # host cores this process may use (the GPU box gives one GPU's share of a big host)
     threads = max(1, min(len(os.sched_getaffinity(0)), L.tor_num_threads(), int(os.environ.get("TORIC_CPU_THREADS", "16"))))
+
+    def timed(n, nthreads, budget):
+        L.tor_set_threads(nthreads)
+        env = CEnvBatch(d, n, p, seed=seed)
+        env.reset()
+        env.actor_steps(2)                                    # page in, spin up the thread team
+        t0 = time.perf_counter()
+        env.actor_steps(4)
+        probe = (time.perf_counter() - t0) / 4
+        steps = int(max(4, min(2000, budget / max(probe, 1e-6))))
+        t0 = time.perf_counter()
+        P, _ = env.actor_steps(steps)
+        dt = time.perf_counter() - t0
+        return n * steps / dt, P / dt, steps, dt
+
+    v, pps, steps, dt = timed(4096, threads, 0.6 * budget_s)
+    out = {"value": v, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
+           "sample": f"4096 lattices x {steps} steps, d={d}, p={p}, C oracle actor loop (OpenMP, {threads} threads), {dt:.1f} s",
+           "perspectives_per_sec": pps}
+    v1, pps1, steps1, dt1 = timed(512, 1, 0.2 * budget_s)
+    out["one_core"] = {"value": v1, "cores": 1, "perspectives_per_sec": pps1,
+                       "sample": f"512 lattices x {steps1} steps, 1 thread, {dt1:.1f} s"}
     L.tor_set_threads(threads)
-    n = 4096
-    env = CEnvBatch(d, n, p, seed=seed)
-    env.reset()
-    env.actor_steps(2)                                        # page in, spin up the thread team
-    t0 = time.perf_counter()
-    env.actor_steps(8)
-    probe = (time.perf_counter() - t0) / 8
-    steps = int(max(4, min(2000, budget_s / max(probe, 1e-6))))
-    t0 = time.perf_counter()
-    P, _ = env.actor_steps(steps)
-    dt = time.perf_counter() - t0
-    out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
-           "sample": f"{n} lattices x {steps} steps, d={d}, p={p}, C oracle actor loop (OpenMP, {threads} threads), {dt:.1f} s",
-           "perspectives_per_sec": P / dt}
-    # the same loop in the reference's own shape (per-lattice python + np.roll), tiny sample
     from oracle import toric_oracle as O
-    oe = O.OracleEnvSet(d, 64, p, seed=seed)
+    n_ref, s_ref = (256, 20) if budget_s >= 5 else (32, 2)    # full SURVEY sample only with a real budget
+    oe = O.OracleEnvSet(d, n_ref, p, seed=seed)
     oe.resetAll()
     t0 = time.perf_counter()
-    O.run_actor_steps_ref(oe, 4, eps=1.0)
-    out["numpy_reference_shaped_steps_per_sec"] = 64 * 4 / (time.perf_counter() - t0)
+    O.run_actor_steps_ref(oe, s_ref, eps=1.0)
+    dtr = time.perf_counter() - t0
+    out["numpy_reference_shaped"] = {"value": n_ref * s_ref / dtr, "cores": 1,
+                                     "sample": f"{n_ref} lattices x {s_ref} steps, per-lattice python + np.roll/np.rot90 "
+                                               f"(the reference's algorithmic form), {dtr:.1f} s"}
+    out["numpy_reference_shaped_steps_per_sec"] = n_ref * s_ref / dtr
     return out
 
 
@@ -110,15 +167,38 @@ class Shard:
     """One sub-shard of this GPU's lattices with its stream and its caller-owned output buffers."""
 
 
+def dry_run(args, world, rank):
+    """TORIC_BENCH_DRY_RUN=1: launcher / rendezvous check only (CPU test of the N>1 command form on a
+    box without a GPU): init the process group, agree on the world size, print a line that says so.
+    Nothing is measured and `value` is null."""
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("TORIC_DIST_BACKEND", "gloo")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    seen = torch.ones(1)
+    dist.all_reduce(seen)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "env steps/sec (batched) at d=%d p=%g" % (args.size, args.p_error), "value": None,
+                          "unit": "env-steps/s", "n_gpus": dist.get_world_size(), "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "ranks_seen": int(seen.item()),
+                          "config": {"workload": "launcher dry run: no GPU work", "collective": backend}}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    if os.environ.get("TORIC_BENCH_DRY_RUN") == "1":
+        return dry_run(args, world, rank)
+
+    import torch
     import torch.distributed as dist
     import toric_rl_decoder_amd as T
     from toric_rl_decoder_amd import gather as G
@@ -139,8 +219,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world
 
-    d, n, K, W = args.size, args.envs, args.steps, args.warmup
+    d, K, W = args.size, args.steps, args.warmup
+    n = args.envs if args.envs is not None else (ENVS_N1 if world == 1 else ENVS_MULTI)
     nq = 2 * d * d
     tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "u8": torch.uint8}[args.out_dtype]
     esize = {"f32": 4, "f16": 2, "bf16": 2, "u8": 1}[args.out_dtype]
@@ -155,18 +237,21 @@ def main():
     if args.graph:
         K = max(flush, K - K % flush)                                  # whole replays
         W = max(flush, W - W % flush)
+    host_delivery = dist_on and not args.no_transitions and args.delivery in ("auto", "host") and backend == "nccl"
 
-    model = None
-    if args.policy == "nn11":
+    def make_model():
         from toric_rl_decoder_amd.policy import NN_11
         torch.manual_seed(0)                                          # random-init weights of the NN_11 architecture
-        model = NN_11(d, 3).to(device).eval()
+        return NN_11(d, 3).to(device).eval()
+
+    model = make_model() if args.policy == "nn11" else None
 
     env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": 0, "p_error": args.p_error})
     first, _ = G.shard_range(n * world, world, rank)
     # worst case every qubit is a hit (exploration grows the defect density): size each stack for
     # that -- 2.5 GB at d=7 f32, 6.9 GB at d=9 for 65 536 lattices -- out of 288 GB of HBM
     cap = ns * nq
+    row = (ns + 2) & ~1                 # offsets rows of even length: every row starts 16-byte aligned (toricenv.h)
     shards = []
     for k in range(S):
         sh = Shard()
@@ -176,24 +261,31 @@ def main():
             sh.envs.resetAll()
             sh.stack = torch.empty((cap, 2, d, d), dtype=tdtype, device=device)
             sh.positions = torch.empty((cap, 3), dtype=torch.int32, device=device)
-            sh.offs = torch.zeros((W + K, ns + 1), dtype=torch.int64, device=device)     # one scan per step: P = row[-1]
+            sh.offs = torch.zeros((2 * (W + K) + args.nn_steps + 2, row), dtype=torch.int64, device=device)  # one scan per step: P = row[ns]
             sh.blocks = None if args.no_transitions else [sh.envs.newTransitionBlock(steps=flush) for _ in range(2)]
             sh.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                      for _ in range(K)] if use_events else []
             sh.wrote = torch.cuda.Event()
-            sh.eps = torch.full((ns,), args.eps, dtype=torch.float64, device=device) if model is not None else None
+            sh.eps = torch.full((ns,), args.eps, dtype=torch.float64, device=device)
+            sh.burn_idx = [torch.arange(t, ns, EPISODE, dtype=torch.int32, device=device) for t in range(EPISODE)]
         shards.append(sh)
     torch.cuda.synchronize(device)
     have_blocks = shards[0].blocks is not None
-    tg = None
-    if dist_on and have_blocks:
-        tg = [G.TransitionGather(sh.blocks[0].nbytes, device, ring_slots=2, host_drain=args.host_drain) for sh in shards]
+
+    def make_gathers(host):
+        if not (dist_on and have_blocks):
+            return None
+        return [G.TransitionGather(sh.blocks[0].nbytes, device, ring_slots=2, host_drain=host) for sh in shards]
+
+    tg = make_gathers(host_delivery)
+    state = {"tg": tg, "model": model}
 
     def one_step(k, t, timed_idx=None):
         sh = shards[k]
+        tg_, model_ = state["tg"], state["model"]
         # one shard: stay on torch's current stream (inside torch.cuda.graph() that is the capture stream)
         with (torch.cuda.stream(sh.stream) if S > 1 else contextlib.nullcontext()):
-            envs, off = sh.envs, sh.offs[t]
+            envs, off = sh.envs, sh.offs[t][:ns + 1]
             envs.perspectiveCounts(off)
             if S > 1:
                 sh.stream.wait_event(shards[(k - 1) % S].wrote)          # one stack write at a time
@@ -206,14 +298,18 @@ def main():
                 sh.wrote.record(sh.stream)
             blk = sh.blocks[(t // flush) & 1] if have_blocks else None
             act = None
-            if model is not None:                                     # configs[2] as written: stack -> NN_11 -> selection
+            if model_ is not None:                                    # configs[2] as written: stack -> NN_11 -> selection
                 P = int(off[-1].item())
                 with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.nn_dtype == "bf16"):
-                    q = torch.cat([model(sh.stack[i:i + 32768]) for i in range(0, P, 32768)]).float()
+                    q = torch.cat([model_(sh.stack[i:min(i + 32768, P)]) for i in range(0, P, 32768)]).float()
                 act, _ = envs.selectAction(q, sh.eps, positions=sh.positions, offsets=off)
             envs.actorStep(act, block=blk, slot=t % flush, want_actions=True)
-            if tg is not None and (t + 1) % flush == 0:
-                tg[k].gather(blk.buf)
+            if blk is not None and (t + 1) % flush == 0:
+                # computePrioritiesParallel into the block (eps = 1: no Q-values, priority = |reward|);
+                # with the NN in the loop the Q rows would be passed here (actor.run_actor does)
+                blk.computePriorities(ns, flush, None, 0.95)
+                if tg_ is not None:
+                    tg_[k].gather(blk.buf)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -221,11 +317,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    if tg is not None:        # RCCL sets its communicator up lazily: pay for that before anything is timed
-        for k, g in enumerate(tg):
-            g.gather(shards[k].blocks[1].buf)
-            g.wait()
+    def warm_collective(gs):     # RCCL sets its communicator up lazily: pay for that before anything is timed
+        if gs is not None:
+            for k, g in enumerate(gs):
+                g.gather(shards[k].blocks[1].buf)
+                g.wait()
+
+    warm_collective(tg)
     barrier()
+
+    # ---- burn-in: stagger the episodes so the population is stationary (not part of warm-up or timing)
+    if not args.no_burn_in:
+        for t in range(EPISODE):
+            for sh in shards:
+                with (torch.cuda.stream(sh.stream) if S > 1 else contextlib.nullcontext()):
+                    if sh.burn_idx[t].numel():
+                        sh.envs.resetTerminalEnvs(sh.burn_idx[t])
+                    sh.envs.actorStep(None, want_actions=False)
+        barrier()
+
     graph = None
     if args.graph:
         # the capture stream is torch's current stream inside torch.cuda.graph(); every ABI call
@@ -239,78 +349,132 @@ def main():
         with torch.cuda.graph(graph):
             for t in range(flush):
                 one_step(0, t)
-                p_acc[t:t + 1].add_(sh0.offs[t, -1:])                 # running sum of P per slot of the window
+                p_acc[t:t + 1].add_(sh0.offs[t, ns:ns + 1])           # running sum of P per slot of the window
         p_acc.zero_()
 
-    def run_steps(first, count, timed):
+    def run_steps(first_t, count, timed):
         if graph is not None:
             for _ in range(count // flush):
                 graph.replay()
             return
         for i in range(count):
             for k in range(S):
-                one_step(k, first + i, i if timed else None)
+                one_step(k, first_t + i, i if timed else None)
 
-    run_steps(0, W, False)
-    barrier()
-    if graph is not None:
-        p_acc.zero_()
-        torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    run_steps(W, K, True)
-    if tg is not None:
-        for k, g in enumerate(tg):
-            with torch.cuda.stream(shards[k].stream):
-                g.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed_region(first_t):
+        """W untimed + K timed steps, bracketed by barrier + synchronize; -> seconds (max over ranks)."""
+        run_steps(first_t, W, False)
+        barrier()
+        if graph is not None:
+            p_acc.zero_()
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        run_steps(first_t + W, K, True)
+        if state["tg"] is not None:
+            for k, g in enumerate(state["tg"]):
+                with torch.cuda.stream(shards[k].stream):
+                    g.wait()
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        if dist_on:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
+    elapsed = timed_region(0)
     for sh in shards:
-        sh.envs.check()                                               # capacity / action latch
+        sh.envs.check()                                               # capacity / action / reset latch
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    if dist_on:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
     if graph is not None:      # slot t of the captured window accumulated its P over the K/flush replays
         p_timed = (p_acc.to(torch.float64) / (K // flush)).repeat(K // flush).reshape(1, -1)
     else:
-        p_timed = torch.stack([sh.offs[W:, -1] for sh in shards]).to(torch.float64)   # (S, K) perspectives per launch
+        p_timed = torch.stack([sh.offs[W:W + K, ns] for sh in shards]).to(torch.float64)   # (S, K) perspectives per launch
     p_sum = p_timed.sum().reshape(1).to(red_dev)
     if dist_on:
         dist.all_reduce(p_sum, op=dist.ReduceOp.SUM)
     total_steps = float(n) * world * K
+    ev_ms = None
+    if use_events:
+        ev_ms = np.array([[a.elapsed_time(b) for a, b in sh.ev] for sh in shards])         # (S, K) launch durations
+
+    # ---- N>1 with host delivery: the same region again with the ring kept in rank 0's HBM
+    hbm_ring = None
+    if host_delivery and graph is None:
+        state["tg"] = make_gathers(False)
+        warm_collective(state["tg"])
+        barrier()
+        el2 = timed_region(W + K)
+        hbm_ring = {"value": total_steps / el2, "ms_per_step": 1e3 * el2 / K,
+                    "note": "same run, transition ring left in rank 0's HBM (no D2H drain)"}
+
+    # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured once at size
+    nn_leg = None
+    if world == 1 and args.nn_steps > 0 and args.policy == "explore" and graph is None and S == 1:
+        state["tg"], state["model"] = None, make_model()
+        sh0 = shards[0]
+        base = W + K
+        one_step(0, base)                                             # warm-up: MIOpen picks its kernels
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(args.nn_steps):
+            one_step(0, base + 1 + i)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        P_nn = float(sh0.offs[base + 1:base + 1 + args.nn_steps, ns].sum().item())
+        flop_per_persp = 2.0 * sum(ci * co * 9 * ((d - 2) ** 2 if i == 10 else d * d)
+                                   for i, (ci, co) in enumerate(zip((2, 128, 128, 120, 111, 104, 103, 90, 80, 73, 71),
+                                                                    (128, 128, 120, 111, 104, 103, 90, 80, 73, 71, 64))))
+        nn_leg = {"workload": "configs[2] as written: %d lattices, d=%d: stack (%s) -> NN_11 (random init, %s, stock torch "
+                              "conv) -> device eps=%g greedy selection -> fused step" % (n, d, args.out_dtype, args.nn_dtype, args.eps),
+                  "steps": args.nn_steps, "env_steps_per_sec": n * args.nn_steps / dt,
+                  "perspectives_per_sec_into_nn": P_nn / dt, "ms_per_step": 1e3 * dt / args.nn_steps,
+                  "nn_dtype": args.nn_dtype, "nn_tflops": P_nn * flop_per_persp / dt / 1e12}
+        state["model"] = None
+        sh0.envs.check()
 
     if rank == 0:
         policy_txt = "policy NN excluded (eps=1 selection in the fused kernel)" if model is None else \
             "NN_11 (random init, %s) forward + eps=%g greedy selection IN the loop" % (args.nn_dtype, args.eps)
+        cfg_name = "configs[2]" if (world == 1 and n == ENVS_N1) else ("configs[4] shape" if n == ENVS_MULTI else "custom")
+        collective = None
+        if dist_on:
+            collective = "transition gather (packed blocks incl. priorities) to rank 0 (%s, %d ranks) every %d steps%s" % (
+                backend, dist.get_world_size(), flush,
+                " + D2H drain of every gathered slot to the pinned host replay ring" if host_delivery else "; ring in rank 0's HBM")
         res = {
             "metric": "env steps/sec (batched) at d=%d p=%g" % (d, args.p_error),
             "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d lattices/GPU, d=%d, p_error=%g; actor-loop pass = "
+            "config": {"workload": "BASELINE %s: %d lattices/GPU, d=%d, p_error=%g; actor-loop pass = "
                                    "perspective stack (%s) + positions -> selection -> step -> transition "
-                                   "record -> auto-reset (max 75 steps/episode); %s" %
-                                   (n, d, args.p_error, args.out_dtype, policy_txt),
+                                   "record -> auto-reset (max 75 steps/episode), priorities every %d steps; %s" %
+                                   (cfg_name, n, d, args.p_error, args.out_dtype, flush, policy_txt),
                        "policy": args.policy, "envs_per_gpu": n, "d": d, "p_error": args.p_error,
                        "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
                        "streams_per_gpu": S, "hip_graph": bool(args.graph), "parallelism": "env-shard x%d" % world,
-                       "collective": None if not dist_on else
-                       "transition gather to rank 0 (%s) every %d steps%s" % (backend, flush, " + D2H drain to pinned host ring" if args.host_drain else "")},
+                       "steady_state": not args.no_burn_in, "delivery": ("host" if host_delivery else "hbm") if dist_on else None,
+                       "collective": collective},
             "perspectives_per_sec": float(p_sum.item()) / elapsed,
+            "perspectives_per_lattice": float(p_sum.item()) / total_steps,
         }
+        if hbm_ring is not None:
+            res["hbm_ring"] = hbm_ring
         if use_events:
-            ms = np.array([[a.elapsed_time(b) for a, b in sh.ev] for sh in shards])     # (S, K) launch durations
             p_mean = float(p_timed.mean().item())
             alg = p_mean * (nq * esize + 12) + ns * nq                 # SURVEY 8(d): P*(B_p+12) + N*2d^2, per launch
-            achieved = alg / (ms.mean() * 1e-3) / 1e9
-            traffic = None
+            achieved = alg / (ev_ms.mean() * 1e-3) / 1e9
+            # HBM bytes from the PMC counters: profiles/pmc_latest.json holds the counters of a profiled run
+            # (tools/pmc_profile.sh: separate --pmc passes, WRITE_SIZE + 2*FETCH_SIZE in KiB units) as bytes per
+            # PERSPECTIVE of that run; scaled by this run's perspectives per launch when shape and dtype match
+            traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
-                    if j.get("envs") == ns and j.get("d") == d and j.get("out_dtype") == args.out_dtype:
-                        traffic = j.get("hbm_bytes_per_launch")
+                    for ent in j.get("entries", []):
+                        if ent.get("d") == d and ent.get("out_dtype") == args.out_dtype:
+                            traffic = ent["hbm_bytes_per_perspective"] * p_mean
+                            traffic_src = ent.get("source")
                 except Exception:
                     traffic = None
             # context (SURVEY 8d): the box's own streaming-fill bandwidth, measured after the timed region
@@ -324,10 +488,14 @@ def main():
             fill_gbps = fb.numel() / (min(fill_ms[1:]) * 1e-3) / 1e9
             res["roofline"] = {"bound": "hbm", "kernel": "k_persp_write", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                               "traffic_over_algorithmic": None if traffic is None else traffic / alg,
+                               "traffic_source": traffic_src,
                                "measured_fill_gbps": fill_gbps, "frac_of_measured_fill": achieved / fill_gbps,
-                               "bytes_per_launch": alg, "avg_launch_ms": float(ms.mean()),
-                               "median_launch_ms": float(np.median(ms)), "perspectives_per_launch": p_mean,
+                               "bytes_per_launch": alg, "avg_launch_ms": float(ev_ms.mean()),
+                               "median_launch_ms": float(np.median(ev_ms)), "perspectives_per_launch": p_mean,
                                "launches_per_step": S, "lattices_per_launch": ns}
+        if nn_leg is not None:
+            res["nn_in_loop"] = nn_leg
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(d, args.p_error, args.seed, args.cpu_seconds)
         print(json.dumps(res), flush=True)

@@ -20,11 +20,17 @@
  *  - a handle is not thread-safe; use one handle per process / GPU
  *    (one actor process per device: Distributed_mp.py:201-211).  Entry points make the handle's
  *    device current while they run and restore the caller's device before returning.
- *  - set-up calls (tq_create, tq_destroy, tq_set_perror_schedule, the first use of a lattice size on
- *    a device) allocate and synchronise; everything else only enqueues kernels.
- *  - the tq_states_* entry points and tq_transition_write share one per-device scratch area that
- *    grows on demand: calls that use it must be issued on one stream (or be separated by a
- *    synchronisation) -- they are stream-ordered, not re-entrant across streams.
+ *  - set-up calls (tq_create, tq_destroy, tq_set_perror_schedule, tq_states_reserve, the first use of a
+ *    lattice size on a device) allocate and synchronise; everything else only enqueues kernels.
+ *    tq_create, tq_destroy and tq_states_reserve leave the caller's current device unchanged.
+ *  - tq_states_persp_count / tq_states_persp_write use one per-device scratch area sized by
+ *    tq_states_reserve (they return TQ_E_CAPACITY when it is too small, they never allocate); calls
+ *    that use it must be issued on one stream or be separated by a synchronisation.
+ *  - alignment: `actions`, `actions_out`, `offsets`, `counts`, `positions` and the stack `out` are
+ *    accessed with 16-byte vector loads/stores and must be 16-byte aligned (TQ_E_INVALID otherwise;
+ *    any hipMalloc / PyTorch allocation is).  For full store bandwidth `out` and `positions` should
+ *    be 128-byte aligned (tq_persp_write writes whole 128-byte lines).  A row of a 2-D int64 offsets
+ *    array needs an even row length.
  *  - RNG: counter-based Philox4x32-10 keyed (seed, global env id, episode, round/step);
  *    contract in DESIGN.md.  Results are identical for any partition of env ids over GPUs.
  */
@@ -37,13 +43,15 @@
 extern "C" {
 #endif
 
-#define TQ_VERSION 100
+#define TQ_VERSION 200      /* 200: packed block carries f32 priority; every slot written (op 0 = no transition) */
 
 #define TQ_OK 0
 #define TQ_E_INVALID (-1)   /* bad argument (NULL handle, even d, unsupported d, n <= 0 ...) */
 #define TQ_E_HIP (-2)       /* a HIP runtime call failed; message in tq_last_error() */
 #define TQ_E_CAPACITY (-3)  /* output capacity too small */
 #define TQ_E_ACTION (-4)    /* an action outside the lattice / op not in 1..3 was seen on the device */
+#define TQ_E_INDEX (-5)     /* tq_reset_idx saw an index out of range or listed twice (latched, tq_check) */
+#define TQ_E_RESET (-6)     /* a reset hit the round limit without producing a defect (latched, tq_check) */
 
 /* element type of the perspective stack written by tq_persp_write */
 #define TQ_F32 0            /* float32 -- what the reference feeds the NN (numba/util_actor.py:39) */
@@ -67,7 +75,7 @@ const char* tq_last_error(void);
 int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_t first_env_id);
 int tq_destroy(tq_env* h);
 
-/* env config: default p_error (gym config "p_error"), terminal reward (default 100,
+/* env config: default p_error in (0,1] (gym config "p_error"), terminal reward (default 100,
  * evaluation.py:175), max_actions_per_episode (default 75, Distributed_mp.py:44; used only by
  * tq_actor_step's auto-reset). */
 int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int max_steps_per_episode);
@@ -79,8 +87,9 @@ int tq_size(const tq_env* h);
 
 /* EnvSet.resetAll(p_errors) (EnvSet.py:29-36): p_err = device f64[N] or NULL (default p). */
 int tq_reset_all(tq_env* h, const double* p_err, void* stream);
-/* EnvSet.resetTerminalEnvs(idx, p_errors) (EnvSet.py:19-27): idx = device i32[n_idx] (distinct),
- * p_err = device f64[n_idx] or NULL. */
+/* EnvSet.resetTerminalEnvs(idx, p_errors) (EnvSet.py:19-27): idx = device i32[n_idx] (distinct,
+ * in range), p_err = device f64[n_idx] or NULL.  Checked on the device: an index out of range is
+ * skipped, of an index listed twice only one copy resets the lattice, and TQ_E_INDEX is latched. */
 int tq_reset_idx(tq_env* h, const int32_t* idx, int n_idx, const double* p_err, void* stream);
 
 /* EnvSet.step(actions) (EnvSet.py:38-47): actions = device i32[N,4]; rewards f32[N];
@@ -116,6 +125,8 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
 
 /* Same two steps for a batch of syndromes that does not live in a handle (the learner's
  * predictMaxOptimized, util_learner.py:48-111): states = device u8[n,2,d,d]. */
+/* set-up: size the calling device's scratch for up to n_max states of size d (allocates, synchronises) */
+int tq_states_reserve(int d, int n_max);
 int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, int64_t* offsets,
                           void* stream);
 int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* offsets, void* out,
@@ -129,6 +140,16 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
 int tq_select_action(tq_env* h, const float* q_table, const int64_t* offsets,
                      const int32_t* positions, const double* eps, int32_t* actions,
                      float* q_values, void* stream);
+
+/* The same selection for an explicit batch of states that does not live in a handle --
+ * selectActionBatch(number_of_actions, epsilon, grid_shift, toric_size, state, model, device)
+ * (numba/util_actor.py:11-53) after the model forward.  The reference draws from numpy's global,
+ * never seeded RNG (:49, :97-98); here the draw of state i is Philox keyed (seed, first_id + i,
+ * call_counter) in its own domain, so the caller supplies a seed and a counter it advances per call. */
+int tq_states_select_action(int n, const float* q_table, const int64_t* offsets,
+                            const int32_t* positions, const double* eps, uint64_t seed,
+                            uint64_t call_counter, int64_t first_id, int32_t* actions,
+                            float* q_values, void* stream);
 
 /* Reads and clears the calling device's error latch of the tq_states_* entry points (synchronises
  * `stream`): 0, TQ_E_ACTION or TQ_E_CAPACITY. */
@@ -155,17 +176,29 @@ int tq_states_transition(int d, int n, const uint8_t* states, const uint8_t* nex
                          const int32_t* actions, uint8_t* persp, uint8_t* next_persp,
                          int32_t* actions_out, void* stream);
 
-/* Packed transition block (the wire format gathered to the replay memory): for `cap`
- * transitions, SoA sections in this order, each 8-byte aligned:
+/* Packed transition block (the wire format gathered to the replay memory -- the (transition,
+ * priority) pairs of Actor_mp.py:152, IO_mp.py:60-66): for `cap` transitions, SoA sections in this
+ * order, each 8-byte aligned:
  *   persp_v u64[W][cap] | persp_p u64[W][cap] | next_v u64[W][cap] | next_p u64[W][cap] |
- *   action u32[cap] (layer | row<<8 | col<<16 | op<<24) | reward f32[cap] | terminal u8[cap]
- * with W = ceil(d*d/64) and bit r*d+c of a plane = cell (r,c). */
+ *   action u32[cap] (layer | row<<8 | col<<16 | op<<24) | reward f32[cap] | priority f32[cap] |
+ *   terminal u8[cap]
+ * with W = ceil(d*d/64) and bit r*d+c of a plane = cell (r,c); 45 bytes per transition at d=7.
+ * A slot whose action word is 0 (op = 0) holds no transition (the lattice was given a no-op or a
+ * rejected action): all its other fields are zero and consumers drop it. */
 int64_t tq_transition_block_bytes(int d, int64_t cap);
-/* unpack slots [first, first+count) of a block into u8 grids / i32 actions / f32 rewards /
- * u8 terminals (any output may be NULL). */
+/* unpack slots [first, first+count) of a block into u8 grids / i32 actions (op 0 = empty slot) /
+ * f32 rewards / u8 terminals / f32 priorities (any output may be NULL). */
 int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, int64_t count,
                          uint8_t* persp, uint8_t* next_persp, int32_t* actions, float* rewards,
-                         uint8_t* terminals, void* stream);
+                         uint8_t* terminals, float* priorities, void* stream);
+/* computePrioritiesParallel (util_actor.py:268-287) into the block's priority section, for a block
+ * that holds n_steps steps of n_envs lattices in slot order t*n_envs + e (what tq_actor_step writes):
+ *   priority = | reward + discount * max_a Q[t+1][e][a] - Q[t][e][op-1] |   (f64 arithmetic, stored f32)
+ * q_values = device f32[n_steps+1][n_envs][3]: the q_values selectActionBatch returned at each of the
+ * n_steps steps plus the step after (local_buffer_Q and its np.roll(-1), Actor_mp.py:146-150);
+ * NULL = all zeros (pure exploration).  Empty slots get priority 0. */
+int tq_block_priorities(int d, void* block, int64_t cap, int n_envs, int n_steps,
+                        const float* q_values, double discount, void* stream);
 
 /* One fused iteration of the actor loop body after the policy (Actor_mp.py:116-183):
  *   step (EnvSet.step) -> transition record (generateTransitionParallel) -> reset of terminal
@@ -175,13 +208,14 @@ int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, i
  * (eps = 1: uniform random perspective and op drawn in-kernel with the same Philox draws as
  * tq_select_action).  Outputs (may be NULL): actions_out i32[N,4] (the actions taken),
  * rewards f32[N], terminals u8[N], block/slot: packed transition block with capacity
- * `block_cap` transitions, lattice e writing slot `slot_base + e`. */
+ * `block_cap` transitions, lattice e writing slot `slot_base + e` (always: an empty slot when it
+ * was given a no-op or a rejected action; the priority section is left to tq_block_priorities). */
 int tq_actor_step(tq_env* h, const int32_t* actions, int32_t* actions_out, float* rewards,
                   uint8_t* terminals, void* block, int64_t block_cap, int64_t slot_base,
                   void* stream);
 
-/* Reads and clears the handle's device error latch (synchronises `stream`): 0, TQ_E_ACTION
- * or TQ_E_CAPACITY. */
+/* Reads and clears the handle's device error latch (synchronises `stream`): 0, TQ_E_ACTION,
+ * TQ_E_CAPACITY, TQ_E_INDEX or TQ_E_RESET. */
 int tq_check(tq_env* h, void* stream);
 
 #ifdef __cplusplus

@@ -56,6 +56,7 @@ import numpy as np
 DOMAIN_ERR = 0
 DOMAIN_SEL = 1
 DOMAIN_PERR = 2
+DOMAIN_SEL_CALL = 3
 MAX_RESET_ROUNDS = 4096
 TERMINAL_REWARD = 100.0  # evaluation.py:175, Learner_mp.py:151 (clamp +-100)
 
@@ -362,8 +363,12 @@ def generate_transition_batch(actions, states, next_states, dtype=np.uint8):
     return per, act, nper
 
 
-def select_action_batch(q_table, offsets, positions, eps, seed, env_ids, episodes, steps):
+def select_action_batch(q_table, offsets, positions, eps, seed, env_ids, episodes, steps, domain=DOMAIN_SEL):
     """_selectActionBatch_prime (numba/util_actor.py:69-107) with Philox draws.
+
+    ``domain=DOMAIN_SEL_CALL`` is the stateless form (selectActionBatch over an explicit state
+    array, numba/util_actor.py:11-53): env_ids = state index, episodes / steps = low / high
+    32 bits of the caller's call counter.
 
     greedy iff (1-eps) > U (:49-50); greedy = first (p,a) attaining the max in
     row-major order (:93-95); else p ~ randint(n), a ~ randint(3) (:97-98);
@@ -374,7 +379,7 @@ def select_action_batch(q_table, offsets, positions, eps, seed, env_ids, episode
     n = offsets.shape[0] - 1
     k0, k1 = _key(seed)
     w0, w1, w2, _ = philox4x32(np.asarray(env_ids, np.uint64), np.asarray(episodes, np.uint64),
-                               np.asarray(steps, np.uint64), np.uint64(DOMAIN_SEL << 24), k0, k1)
+                               np.asarray(steps, np.uint64), np.uint64(domain << 24), k0, k1)
     w0, w1, w2 = (np.broadcast_to(w, (n,)) for w in (w0, w1, w2))
     eps = np.broadcast_to(np.asarray(eps, np.float64), (n,))
     greedy = (1.0 - eps) > _u01(w0)
@@ -400,6 +405,18 @@ def select_action_batch(q_table, offsets, positions, eps, seed, env_ids, episode
         actions[i, :3] = positions[lo + p]
         actions[i, 3] = a + 1
     return actions, qv, chosen
+
+
+def compute_priorities(A, R, Q, Qns, discount):
+    """computePrioritiesParallel (util_actor.py:268-287): |R + discount * max_a Qns - Q[a]| with the
+    reference's dtypes (its local buffers are f64 arrays, Actor_mp.py:65-70) -> f64 (N,T)."""
+    A, R = np.asarray(A), np.asarray(R, np.float64)
+    Q, Qns = np.asarray(Q, np.float64), np.asarray(Qns, np.float64)
+    qns_max = np.amax(Qns, axis=2)
+    actions = A[:, :, -1].astype(np.int64) - 1
+    row = np.arange(actions.shape[-1])
+    qv = np.array([Q[env, row, actions[env]] for env in range(len(Q))])
+    return np.absolute(R + discount * qns_max - qv)
 
 
 def perror_schedule(seed, env_ids, episodes, p_start, p_roof, strategy):

@@ -36,10 +36,15 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_block_layout(lib):
-    assert lib.tq_version() == 100
-    # d=7: W=1 -> 4*8 + 4 + 4 + 1 bytes per transition, sections 8-byte aligned
-    assert lib.tq_transition_block_bytes(7, 8) == 4 * 8 * 8 + 32 + 32 + 8
-    assert lib.tq_transition_block_bytes(9, 1000) == 4 * 8 * 2 * 1000 + 4000 + 4000 + 1000
+    assert lib.tq_version() == 200
+    # d=7: W=1 -> 4*8 + 4 + 4 + 4 + 1 bytes per transition (planes, action, reward, priority, terminal),
+    # sections 8-byte aligned
+    assert lib.tq_transition_block_bytes(7, 8) == 4 * 8 * 8 + 32 + 32 + 32 + 8
+    assert lib.tq_transition_block_bytes(9, 1000) == 4 * 8 * 2 * 1000 + 3 * 4000 + 1000
+    from toric_rl_decoder_amd import wire
+    for d in (3, 5, 7, 9, 11):
+        for cap in (1, 7, 64, 1000, 65536):
+            assert lib.tq_transition_block_bytes(d, cap) == wire.block_bytes(d, cap)
     assert lib.tq_transition_block_bytes(4, 8) == -1
     assert lib.tq_transition_block_bytes(7, -1) == -1
 
@@ -52,6 +57,8 @@ def test_errors_are_codes_not_aborts(lib):
     assert rc == _lib.TQ_E_INVALID and b"unsupported lattice size" in lib.tq_last_error()
     assert lib.tq_set_params(None, 0.1, 100.0, 75) == _lib.TQ_E_INVALID
     assert lib.tq_destroy(None) == 0
+    assert lib.tq_states_reserve(4, 10) == _lib.TQ_E_INVALID and lib.tq_states_reserve(7, 0) == _lib.TQ_E_INVALID
+    assert lib.tq_block_priorities(7, None, 8, 4, 2, None, 0.95, None) == _lib.TQ_E_INVALID
     if not torch.cuda.is_available():
         rc = lib.tq_create(C.byref(h), 8, 7, 0, 1, 0)       # no HIP device: an error code, not a crash
         assert rc < 0 and lib.tq_last_error()

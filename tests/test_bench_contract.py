@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "nn_in_loop", "perspectives_per_lattice"}
 
 
 def test_cpu_baseline_leg_runs_without_gpu():
@@ -20,10 +20,55 @@ def test_cpu_baseline_leg_runs_without_gpu():
     assert out["numpy_reference_shaped_steps_per_sec"] > 0
 
 
+def test_self_launcher_starts_the_ranks_and_relays_one_line():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it (the driver's command form)
+    must start the two ranks itself and print exactly one JSON line with n_gpus == 2.  No GPU here:
+    TORIC_BENCH_DRY_RUN=1 makes the ranks stop after the rendezvous (gloo) -- the launcher, the
+    argument pass-through, the relay of rank 0's line and the exit code are what is checked."""
+    env = dict(os.environ, TORIC_BENCH_DRY_RUN="1", TORIC_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["steps"] == 7 and j["warmup"] == 3 and j["dry_run"] is True
+
+
+def test_self_launcher_propagates_a_rank_failure():
+    env = dict(os.environ, TORIC_BENCH_DRY_RUN="1", TORIC_DIST_BACKEND="no-such-backend")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu():
+    """The N>1 path for real on a one-GPU box: the self-launcher starts two ranks that both use cuda:0
+    (TORIC_SHARE_GPU=1) and exchange their packed transition blocks, priorities included, through
+    gloo (RCCL refuses two ranks on one device)."""
+    env = dict(os.environ, TORIC_DIST_BACKEND="gloo", TORIC_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "8",
+                        "--envs", "4096", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["envs_per_gpu"] == 4096
+    assert "2 ranks" in j["config"]["collective"] and j["value"] > 1e6
+    assert abs(j["value"] - 2 * 4096 * 16 / (j["ms_per_step"] * 16e-3)) / j["value"] < 1e-6
+
+
 @pytest.mark.gpu
 def test_bench_json_contract():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--envs", "8192",
-                        "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600)
+                        "--cpu-seconds", "0.5", "--nn-steps", "1"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -35,8 +80,12 @@ def test_bench_json_contract():
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 100
+    assert r["traffic"] is None or 0.9 < r["traffic_over_algorithmic"] < 1.3
     c = j["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["one_core"]["value"] > 0
+    nn = j["nn_in_loop"]
+    assert nn["steps"] == 1 and nn["perspectives_per_sec_into_nn"] > 1e4 and nn["env_steps_per_sec"] > 100
+    assert j["config"]["steady_state"] is True and 40 < j["perspectives_per_lattice"] < 98
     assert j["value"] > 1e6 and abs(j["value"] - 8192 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6
 
 
@@ -45,7 +94,7 @@ def test_bench_graph_mode():
     """--graph: the flush window captured into a HIP graph (every ABI call is capture-safe: no allocation,
     no synchronisation, caller's stream) and replayed; same JSON contract minus the per-launch roofline."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "32", "--warmup", "8", "--envs", "2048",
-                        "--cpu-seconds", "0", "--graph"], capture_output=True, text=True, timeout=600)
+                        "--cpu-seconds", "0", "--nn-steps", "0", "--graph"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     j = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
     assert j["config"]["hip_graph"] is True and "roofline" not in j

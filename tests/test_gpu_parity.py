@@ -399,8 +399,8 @@ def test_toric_env_facade(T):
 # ------------------------------------------------------------------ BASELINE full sizes
 @pytest.mark.parametrize("d,p,n", [(7, 0.10, 65536), (9, 0.15, 65536)])
 def test_full_size_configs(T, d, p, n):
-    """configs[2] / configs[3]: exact counts/offsets against the oracle for all 65 536 lattices,
-    exact stack compare on a strided subset, and size-independent properties on the whole stack:
+    """configs[2] / configs[3]: exact counts/offsets/positions AND the exact stack against the oracle
+    for all 65 536 lattices, plus size-independent properties on the whole stack:
     every perspective is a permutation of its lattice's syndrome (equal defect count) and has a
     defect on one of the four centre checks (centred-frame property)."""
     gpu, _ = make_pair(T, d, n, p=p, seed=2020, numpy_io=False)
@@ -429,12 +429,22 @@ def test_full_size_configs(T, d, p, n):
     centre = per[:, 0, gs, gs] + per[:, 0, gs + 1, gs] + per[:, 1, gs, gs] + per[:, 1, gs, gs - 1]
     assert bool((centre > 0).all())
     assert bool(((per == 0) | (per == 1)).all())
-    # exact compare on a strided subset of lattices (first, last, every 97th)
+    # exact compare of the WHOLE stack, all 65 536 lattices, against the C oracle (OpenMP, seconds):
+    # the oracle's u8 stack is uploaded and compared on the device in chunks
+    from oracle.c_oracle import CEnvBatch
+    ce = CEnvBatch(d, n, p, seed=2020)
+    cper, cpos, ccnt, coff = ce.perspectives(states=st_np, dtype=np.uint8)
+    assert np.array_equal(ccnt, ocnt) and np.array_equal(coff, off) and np.array_equal(cpos, pos.cpu().numpy())
+    assert cper.shape[0] == per.shape[0]
+    step = 1 << 20
+    for i in range(0, cper.shape[0], step):
+        want = torch.as_tensor(cper[i:i + step], device=per.device)
+        assert torch.equal(per[i:i + step], want.to(torch.float32)), f"stack differs in perspectives [{i}, {i + step})"
+    # and the numpy batch oracle on a strided subset (ties the C oracle to the golden-pinned numpy one here too)
     sel = np.unique(np.concatenate((np.arange(0, n, 97), [n - 1])))
     bp, _, _, _ = O.generate_perspective_batch(st_np[sel])
     rows = np.concatenate([np.arange(off[e], off[e + 1]) for e in sel])
-    got = per[torch.as_tensor(rows, device=per.device)].cpu().numpy()
-    assert np.array_equal(got, bp.astype(np.float32))
+    assert np.array_equal(cper[rows], bp)
     gpu.close()
 
 
@@ -463,4 +473,155 @@ def test_long_run_matches_c_oracle_actor_loop(T, d, n, steps):
     assert np.array_equal(ep.cpu().numpy().astype(np.uint32), ce.episodes) and np.array_equal(st.cpu().numpy().astype(np.uint32), ce.steps)
     assert ce.episodes.min() >= 2 and ce.episodes.max() >= 3          # every lattice was reset at least once
     gpu.check()
+    gpu.close()
+
+
+# ------------------------------------------------------------------ BASELINE configs[0] on the HIP path
+def test_config0_single_env_d3_100_random_steps(T):
+    """configs[0] (1 env, d=3, p_error=0.1, 100 random-action steps through the EnvSet surface, numpy
+    in / numpy out) on the HIP path, every array of every step against the oracle."""
+    d = 3
+    gpu, ora = make_pair(T, d, 1, p=0.1, seed=11)
+    assert np.array_equal(gpu.resetAll(), ora.resetAll())
+    rng = np.random.default_rng(0)
+    episodes = 0
+    for t in range(100):
+        per, pos, cnt = gpu.generatePerspective()
+        bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+        assert np.array_equal(per, bp.astype(np.float32)) and np.array_equal(pos, bpos) and np.array_equal(cnt, bcnt)
+        a = random_actions_from(bpos, boff, rng)                  # eps = 1 branch of _selectActionBatch_prime
+        ns, r, term, _ = gpu.step(a)
+        ons, orr, oterm, _ = ora.step(a)
+        assert np.array_equal(ns, ons) and np.array_equal(r, orr) and np.array_equal(term, oterm)
+        assert np.array_equal(gpu.getQubits(), ora.qubits)
+        if term[0] or ora.steps[0] > 75:
+            assert np.array_equal(gpu.resetTerminalEnvs([0]), ora.resetTerminalEnvs([0]))
+            episodes += 1
+    assert episodes >= 1
+    gpu.close()
+
+
+# ------------------------------------------------------------------ ABI hygiene
+def test_reset_idx_is_validated_on_the_device(T):
+    """Duplicate or out-of-range indices are detected by the kernel itself (device-tensor path, no
+    host-side check): the lattice is reset once, the rest are untouched, and tq_check reports it."""
+    d, n = 5, 300
+    gpu, ora = make_pair(T, d, n, seed=5, numpy_io=False)
+    gpu.resetAll()
+    ora.resetAll()
+    before = gpu.getStates().clone()
+    idx = torch.tensor([4, 9, 4, 17], dtype=torch.int32, device=gpu.device)
+    gpu.resetTerminalEnvs(idx)
+    with pytest.raises(ValueError, match="more than once"):
+        gpu.check()
+    ora.resetTerminalEnvs([4, 9, 17])
+    assert np.array_equal(gpu.getStates().cpu().numpy(), ora.states)        # 4 was reset exactly once
+    ep, _ = gpu.getCounters()
+    assert np.array_equal(ep.cpu().numpy(), ora.episodes)
+    gpu.check()                                                            # latch cleared
+    gpu.resetTerminalEnvs(torch.tensor([1, n, -3], dtype=torch.int32, device=gpu.device))
+    with pytest.raises(ValueError, match="outside"):
+        gpu.check()
+    ora.resetTerminalEnvs([1])
+    assert np.array_equal(gpu.getStates().cpu().numpy(), ora.states)
+    # the same index in two different calls is fine
+    gpu.resetTerminalEnvs(torch.tensor([4], dtype=torch.int32, device=gpu.device))
+    gpu.resetTerminalEnvs(torch.tensor([4], dtype=torch.int32, device=gpu.device))
+    gpu.check()
+    assert not torch.equal(before, gpu.getStates())
+    gpu.close()
+
+
+def test_p_error_zero_is_rejected_or_latched(T):
+    import ctypes as C
+    d, n = 5, 64
+    env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+    gpu = T.EnvSet(env, n, seed=1, numpy_io=False)
+    L = T.load()
+    assert L.tq_set_params(gpu._h, 0.0, 100.0, 75) == -1 and b"(0,1]" in L.tq_last_error()
+    with pytest.raises(ValueError):
+        gpu.set_perror_schedule("linear", 0.0, 0.2, 0.01)
+    # p = 0 smuggled in through the device array: bounded number of rounds, then TQ_E_RESET is latched
+    gpu.resetAll(torch.zeros(n, dtype=torch.float64, device=gpu.device))
+    with pytest.raises(T.ToricEnvError, match="rounds"):
+        gpu.check()
+    gpu.resetAll()
+    gpu.check()
+    assert C.c_int(L.tq_version()).value == 200
+    gpu.close()
+
+
+def test_every_slot_is_written_and_noop_slots_are_empty(T):
+    """tq_actor_step writes its slot every step: a lattice given a no-op leaves an EMPTY slot (action
+    word 0, zero planes), never the record of an earlier flush; wire.decode drops it."""
+    from toric_rl_decoder_amd import wire
+    d, n = 7, 500
+    gpu, ora = make_pair(T, d, n, seed=12, numpy_io=False, max_steps_per_episode=1000)
+    gpu.resetAll()
+    blk = gpu.newTransitionBlock(steps=1)
+    gpu.perspectiveCounts()
+    gpu.actorStep(None, block=blk, slot=0)                    # flush 1: every slot holds a transition
+    assert (blk.unpack()["action"][:, 3] >= 1).all()
+    per, pos, cnt = gpu.generatePerspective(dtype=torch.uint8)
+    act, _ = gpu.selectAction(None, 1.0, positions=pos)
+    act = act.clone()
+    hole = torch.arange(0, n, 7, device=gpu.device)
+    act[hole] = 0                                             # no-op for every 7th lattice
+    gpu.actorStep(act, block=blk, slot=0)                     # flush 2 re-uses the block
+    gpu.check()                                               # a no-op is not an error
+    u = blk.unpack()
+    a = u["action"].cpu().numpy()
+    h = hole.cpu().numpy()
+    assert (a[h] == 0).all() and not u["perspective"][hole].any() and not u["next_perspective"][hole].any()
+    assert not u["reward"][hole].any() and not u["terminal"][hole].any()
+    dec = wire.decode(blk.buf.cpu().numpy(), d, n)
+    assert dec["perspective"].shape[0] == n - h.size and np.array_equal(dec["slot"], np.setdiff1d(np.arange(n), h))
+    gpu.close()
+
+
+def test_alignment_and_scratch_contract(T):
+    """16-byte alignment of vector-accessed arguments is checked (TQ_E_INVALID, no kernel launched);
+    the stateless scratch is sized by tq_states_reserve and never re-allocated by a hot-path call;
+    tq_create leaves the caller's current device alone."""
+    import ctypes as C
+    L = T.load()
+    d, n = 7, 256
+    cur = torch.cuda.current_device()
+    gpu, _ = make_pair(T, d, n, seed=2, numpy_io=False)
+    assert torch.cuda.current_device() == cur
+    gpu.resetAll()
+    offs = torch.zeros(n + 3, dtype=torch.int64, device=gpu.device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.tq_persp_count(gpu._h, None, C.c_void_p(offs.data_ptr() + 8), stream)
+    assert rc == -1 and b"16-byte" in L.tq_last_error()
+    assert L.tq_persp_count(gpu._h, None, C.c_void_p(offs.data_ptr() + 16), stream) == 0
+    acts = torch.zeros(4 * n + 4, dtype=torch.int32, device=gpu.device)
+    assert L.tq_step(gpu._h, C.c_void_p(acts.data_ptr() + 4), None, None, stream) == -1
+    out = torch.zeros(n * 98 * 98 + 64, dtype=torch.uint8, device=gpu.device)
+    rc = L.tq_persp_write(gpu._h, C.c_void_p(offs.data_ptr() + 16), C.c_void_p(out.data_ptr() + 4), None, n * 98, 3, stream)
+    assert rc == -1
+    # stateless scratch: too small -> error code, not a re-allocation in the middle of the stream
+    big = 1 << 16
+    st = torch.zeros((big, 2, 11, 11), dtype=torch.uint8, device=gpu.device)
+    o2 = torch.zeros(big + 1, dtype=torch.int64, device=gpu.device)
+    rc = L.tq_states_persp_count(11, big, C.c_void_p(st.data_ptr()), None, C.c_void_p(o2.data_ptr()), stream)
+    if rc != 0:                                               # (0 only if an earlier test already reserved this much)
+        assert rc == -3 and b"tq_states_reserve" in L.tq_last_error()
+    assert L.tq_states_reserve(11, big) == 0
+    assert L.tq_states_persp_count(11, big, C.c_void_p(st.data_ptr()), None, C.c_void_p(o2.data_ptr()), stream) == 0
+    torch.cuda.synchronize()
+    assert int(o2[-1]) == 0
+    gpu.close()
+
+
+def test_generate_perspective_of_explicit_states(T):
+    """EnvSet.generatePerspective(states=...): the reference function's explicit-state form."""
+    d, n = 5, 200
+    gpu, ora = make_pair(T, d, n, seed=3)
+    gpu.resetAll()
+    _, other = O.reset_lattices(77, np.arange(50), 0, 0.2, d)
+    per, pos, cnt = gpu.generatePerspective(states=other.astype(np.int64))
+    bp, bpos, bcnt, _ = O.generate_perspective_batch(other)
+    assert per.dtype == np.float32 and np.array_equal(per, bp.astype(np.float32))
+    assert np.array_equal(pos, bpos) and np.array_equal(cnt, bcnt)
     gpu.close()

@@ -43,7 +43,7 @@ def test_select_action_batch_with_model(T, d):
     rng = np.random.default_rng(d)
     for t in range(10):
         eps = rng.random(n) * 0.6
-        act, qv = T.selectActionBatch(gpu, model, eps)
+        act, qv = T.selectActionEnvSet(gpu, model, eps)
         bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
         oact, oqv, _ = O.select_action_batch(oracle_q(model, bp), boff, bpos, eps, ora.seed, ora.env_ids,
                                              ora.episodes, ora.steps)
@@ -116,7 +116,9 @@ def test_evaluate_matches_oracle_loop(T):
 
 def test_actor_loop_matches_oracle_loop(T):
     """run_actor (Actor_mp.py:104-185 on the device) against the same loop spelled with oracle
-    calls: transitions of every buffer column and the priorities of computePrioritiesParallel."""
+    calls: the transitions of the buffer columns that are sent and, in the same packed block, the
+    priorities of computePrioritiesParallel (f64 arithmetic as upstream, stored as f32: bit-equal)."""
+    from toric_rl_decoder_amd import wire
     d, n, buf, flushes, max_steps = 5, 300, 4, 3, 6
     env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
     gpu = T.EnvSet(env, n, seed=31, numpy_io=False, max_steps_per_episode=max_steps)
@@ -127,10 +129,10 @@ def test_actor_loop_matches_oracle_loop(T):
     eps = 0.3
     gen = T.run_actor(gpu, model, flushes, buf, eps, discount_factor=0.95)
     for f in range(flushes):
-        blk, prio = next(gen)
+        blk = next(gen)
         A = np.zeros((n, buf + 1, 4), np.int64)
-        Q = np.zeros((n, buf + 1, 3), np.float32)
-        R = np.zeros((n, buf + 1), np.float32)
+        Q = np.zeros((n, buf + 1), dtype=(np.float64, 3))       # local_buffer_Q is an f64 array (Actor_mp.py:69)
+        R = np.zeros((n, buf + 1))
         trans = []
         for t in range(buf + 1):
             bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
@@ -143,18 +145,191 @@ def test_actor_loop_matches_oracle_loop(T):
             idx = np.nonzero(term | (ora.steps > max_steps))[0]
             if idx.size:
                 ora.resetTerminalEnvs(idx)
-        q_taken = np.take_along_axis(Q[:, :-1], (A[:, :-1, 3] - 1)[..., None], axis=2)[..., 0]
-        want = np.abs(R[:, :-1] + np.float32(0.95) * np.roll(Q, -1, axis=1)[:, :-1].max(axis=2) - q_taken)
-        assert np.allclose(prio.cpu().numpy(), want, rtol=0, atol=1e-6)
-        for t in (0, buf):
+        want = O.compute_priorities(A[:, :-1], R[:, :-1], Q[:, :-1], np.roll(Q, -1, axis=1)[:, :-1], 0.95)
+        for t in range(buf):
             u = blk.unpack(first=t * n, count=n)
             per, act_c, nper, rew, term = trans[t]
             assert np.array_equal(u["perspective"].cpu().numpy(), per)
             assert np.array_equal(u["next_perspective"].cpu().numpy(), nper)
             assert np.array_equal(u["action"].cpu().numpy(), act_c)
             assert np.array_equal(u["reward"].cpu().numpy(), rew)
+            assert np.array_equal(u["terminal"].cpu().numpy().astype(bool), term)
+            assert np.array_equal(u["priority"].cpu().numpy(), want[:, t].astype(np.float32))
+        # host ingest of the same block: the (transition, priority) list of Actor_mp.py:152
+        rec, pr = wire.to_records(wire.decode(blk.buf.cpu().numpy(), d, blk.capacity), d)
+        assert rec.shape[0] == n * buf and np.array_equal(pr.reshape(buf, n).T, want.astype(np.float32))
         assert np.array_equal(gpu.getStates().cpu().numpy(), ora.states)
     gpu.close()
+
+
+def test_actor_mp_call_sequence_with_reference_signatures(T):
+    """The loop body of src/Actor_mp.py:104-183 typed out with the reference's own names, keyword
+    arguments and numpy buffers -- only the imports differ -- against the same loop on the oracle."""
+    from toric_rl_decoder_amd import (EnvSet, computePrioritiesParallel, generateTransitionParallel, make,
+                                      seed_select, selectActionBatch)
+    args = {"device": "cuda", "discount_factor": 0.95, "no_envs": 150, "epsilon_final": [0.2],
+            "env_p_error_start": 0.1, "env_p_error_final": 0.2, "env_p_error_delta": 0.02,
+            "env_p_error_strategy": "linear", "env": "toric-code-v0",
+            "env_config": {"size": 5, "min_qubit_errors": 0, "p_error": 0.1},
+            "size_local_memory_buffer": 3, "max_actions_per_episode": 5}
+    device, discount_factor, no_envs = args["device"], args["discount_factor"], args["no_envs"]
+    epsilon = np.ones(no_envs) * 0.35
+    env_p_error_start, env_p_error_final = args["env_p_error_start"], args["env_p_error_final"]
+    env_p_error_delta, env_p_error_strategy = args["env_p_error_delta"], args["env_p_error_strategy"]
+    env_p_errors = np.ones(no_envs) * env_p_error_start
+    env = make(args["env"], config=args["env_config"], seed=404)
+    envs = EnvSet(env, no_envs)
+    size = env.system_size
+    action_type = np.dtype([('position', (np.int64, 3)), ('op', np.int64)])          # src/util.py:10
+    transition_type = np.dtype([('perspective', (np.int64, (2, size, size))), ('action', action_type),
+                                ('reward', np.float64), ('next_perspective', (np.int64, (2, size, size))),
+                                ('terminal', np.bool_)])
+    no_actions = int(env.action_space.high[-1])
+    grid_shift = int(size / 2)
+    model = IntQ(size, seed=6).to(device)
+    state = envs.resetAll(p_errors=env_p_errors)
+    steps_per_episode = np.zeros(no_envs)
+    size_local_memory_buffer = args["size_local_memory_buffer"] + 1
+    local_buffer_T = np.empty((no_envs, size_local_memory_buffer), dtype=transition_type)
+    local_buffer_A = np.empty((no_envs, size_local_memory_buffer, 4), dtype=np.int64)
+    local_buffer_Q = np.empty((no_envs, size_local_memory_buffer), dtype=(np.float64, 3))
+    local_buffer_R = np.empty((no_envs, size_local_memory_buffer))
+    buffer_idx = 0
+    sent = []
+
+    # the oracle's copy of the loop state
+    ora = O.OracleEnvSet(size, no_envs, 0.1, seed=404)
+    o_state = ora.resetAll(p_errors=env_p_errors)
+    assert np.array_equal(state, o_state) and state.dtype == np.int64
+    o_T = np.empty((no_envs, size_local_memory_buffer), dtype=transition_type)
+    o_A, o_Q, o_R = np.empty_like(local_buffer_A), np.empty_like(local_buffer_Q), np.empty_like(local_buffer_R)
+    seed_select(2024)
+    resets = 0
+    for it in range(3 * size_local_memory_buffer):
+        steps_per_episode += 1
+        action, q_values = selectActionBatch(number_of_actions=no_actions, epsilon=epsilon, grid_shift=grid_shift,
+                                             toric_size=size, state=state, model=model, device=device)
+        next_state, reward, terminal_state, _ = envs.step(action)
+        transition = generateTransitionParallel(action, reward, state, next_state, terminal_state, grid_shift,
+                                                transition_type)
+        # ---- oracle: the same three calls
+        bp, bpos, bcnt, boff = O.generate_perspective_batch(o_state.astype(np.uint8))
+        o_action, o_q, _ = O.select_action_batch(oracle_q(model, bp), boff, bpos, epsilon, 2024, np.arange(no_envs),
+                                                 it & 0xFFFFFFFF, it >> 32, domain=O.DOMAIN_SEL_CALL)
+        o_next, o_reward, o_term, _ = ora.step(o_action)
+        o_tr = O.generate_transition_ref(o_action, o_reward, o_state, o_next, o_term, grid_shift)
+        assert action.dtype == np.int64 and q_values.dtype == np.float64 and q_values.shape == (no_envs, 3)
+        assert np.array_equal(action, o_action) and np.array_equal(q_values, o_q.astype(np.float64))
+        assert np.array_equal(next_state, o_next) and np.array_equal(reward, o_reward)
+        assert np.array_equal(terminal_state, o_term) and reward.dtype == np.float64
+        assert transition.dtype == transition_type
+        for k in ("perspective", "next_perspective"):
+            assert np.array_equal(transition[k], o_tr[k])
+        assert np.array_equal(transition["action"]["position"], o_tr["position"])
+        assert np.array_equal(transition["action"]["op"], o_tr["op"])
+        assert np.array_equal(transition["reward"], o_reward) and np.array_equal(transition["terminal"], o_term)
+
+        local_buffer_T[:, buffer_idx] = transition
+        local_buffer_A[:, buffer_idx] = action
+        local_buffer_Q[:, buffer_idx] = q_values
+        local_buffer_R[:, buffer_idx] = reward
+        o_T[:, buffer_idx] = transition
+        o_A[:, buffer_idx], o_Q[:, buffer_idx], o_R[:, buffer_idx] = o_action, o_q, o_reward
+        buffer_idx += 1
+        if buffer_idx >= size_local_memory_buffer:
+            priorities = computePrioritiesParallel(local_buffer_A[:, :-1], local_buffer_R[:, :-1], local_buffer_Q[:, :-1],
+                                                   np.roll(local_buffer_Q, -1, axis=1)[:, :-1], discount_factor)
+            to_send = [*zip(local_buffer_T[:, :-1].flatten(), priorities.flatten())]
+            want = O.compute_priorities(o_A[:, :-1], o_R[:, :-1], o_Q[:, :-1], np.roll(o_Q, -1, axis=1)[:, :-1],
+                                        discount_factor)
+            assert priorities.dtype == np.float64 and np.array_equal(priorities, want)
+            assert len(to_send) == no_envs * (size_local_memory_buffer - 1)
+            sent.append(to_send)
+            buffer_idx = 0
+        too_many_steps = steps_per_episode > args["max_actions_per_episode"]
+        if np.any(terminal_state) or np.any(too_many_steps):
+            idx = np.argwhere(np.logical_or(terminal_state, too_many_steps)).flatten()
+            env_p_errors[idx] = np.minimum(env_p_error_final, env_p_errors[idx] + env_p_error_delta)
+            if env_p_error_strategy == 'random':
+                p_errors = np.random.uniform(env_p_error_start, env_p_errors[idx])
+            else:
+                p_errors = env_p_errors[idx]
+            reset_states = envs.resetTerminalEnvs(idx, p_errors=p_errors)
+            o_reset = ora.resetTerminalEnvs(idx, p_errors)
+            assert reset_states.dtype == np.float64 and np.array_equal(reset_states, o_reset)   # EnvSet.py:20 quirk
+            next_state[idx] = reset_states
+            o_next[idx] = o_reset
+            steps_per_episode[idx] = 0
+            resets += idx.size
+        state = next_state
+        o_state = o_next
+    assert len(sent) == 3 and resets > no_envs
+    envs.close()
+
+
+def test_stateless_select_action_edge_cases(T):
+    """selectActionBatch over explicit states: scalar epsilon, greedy ties (first maximum), a state
+    without defects (the reference would raise, numba/util_actor.py:93: here op 0), argument checks."""
+    d, n = 7, 64
+    _, st = O.reset_lattices(9, np.arange(n), 0, 0.1, d)
+    st[5] = 0
+    model = IntQ(d, seed=4).cuda()
+    T.seed_select(7, calls=(1 << 32) + 5)                      # a call counter beyond 32 bits
+    act, qv = T.selectActionBatch(3, 0.0, d // 2, d, st.astype(np.int64), model, "cuda")
+    bp, bpos, bcnt, boff = O.generate_perspective_batch(st)
+    oact, oqv, _ = O.select_action_batch(oracle_q(model, bp), boff, bpos, 0.0, 7, np.arange(n), 5, 1,
+                                         domain=O.DOMAIN_SEL_CALL)
+    assert np.array_equal(act, oact) and np.array_equal(qv, oqv.astype(np.float64))
+    assert tuple(act[5]) == (0, 0, 0, 0) and not qv[5].any()
+    act2, _ = T.selectActionBatch(3, 1.0, d // 2, d, st, model, "cuda")         # next call: new draws
+    oact2, _, _ = O.select_action_batch(oracle_q(model, bp), boff, bpos, 1.0, 7, np.arange(n), 6, 1,
+                                        domain=O.DOMAIN_SEL_CALL)
+    assert np.array_equal(act2, oact2) and not np.array_equal(act2, act)
+    with pytest.raises(ValueError):
+        T.selectActionBatch(4, 0.0, d // 2, d, st, model, "cuda")
+    with pytest.raises(ValueError):
+        T.selectActionBatch(3, 0.0, 1, d, st, model, "cuda")
+    with pytest.raises(ValueError):
+        T.selectActionBatch(3, 0.0, d // 2, d, st, model, "cpu")
+
+
+def test_compute_priorities_numpy_and_block_kernel(T):
+    """computePrioritiesParallel: numpy in/out (reference dtypes) and the device kernel over a packed
+    block, both against the oracle restatement; empty slots get priority 0."""
+    from toric_rl_decoder_amd import wire
+    rng = np.random.default_rng(3)
+    d, n, steps = 7, 333, 5
+    A = np.stack((rng.integers(0, 2, (n, steps)), rng.integers(0, d, (n, steps)), rng.integers(0, d, (n, steps)),
+                  rng.integers(1, 4, (n, steps))), axis=2)
+    Qall = rng.standard_normal((n, steps + 1, 3)).astype(np.float32).astype(np.float64) * 50
+    R = rng.integers(-4, 5, (n, steps)).astype(np.float64)
+    R[rng.random((n, steps)) < 0.1] = 100.0
+    want = O.compute_priorities(A, R, Qall[:, :-1], Qall[:, 1:], 0.95)
+    got = T.computePrioritiesParallel(A, R, Qall[:, :-1], Qall[:, 1:], 0.95)
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+    dev = torch.device("cuda")
+    got_t = T.computePrioritiesParallel(torch.as_tensor(A, device=dev), torch.as_tensor(R, device=dev),
+                                        torch.as_tensor(Qall[:, :-1], device=dev), torch.as_tensor(Qall[:, 1:], device=dev), 0.95)
+    assert np.array_equal(got_t.cpu().numpy(), want)
+    # block kernel: slots t*n + e
+    zeros = np.zeros((n * steps, 2, d, d), np.uint8)
+    act_slots = A.transpose(1, 0, 2).reshape(-1, 4).copy()
+    hole = rng.random(n * steps) < 0.05
+    act_slots[hole] = 0
+    buf = wire.encode(d, zeros, zeros, act_slots, R.T.reshape(-1), np.zeros(n * steps, bool))
+    blk = T.TransitionBlock(d, n * steps, dev)
+    blk.buf.copy_(torch.as_tensor(buf, device=dev))
+    q_dev = torch.as_tensor(Qall.transpose(1, 0, 2).astype(np.float32).copy(), device=dev)     # (steps+1, n, 3)
+    blk.computePriorities(n, steps, q_dev, 0.95)
+    pr = blk.unpack()["priority"].cpu().numpy()
+    w32 = want.T.reshape(-1).astype(np.float32)
+    w32[hole] = 0
+    assert np.array_equal(pr, w32)
+    blk.computePriorities(n, steps, None, 0.95)                 # no Q-values: |reward|
+    pr0 = blk.unpack()["priority"].cpu().numpy()
+    assert np.array_equal(pr0, np.where(hole, 0, np.abs(R.T.reshape(-1))).astype(np.float32))
+    with pytest.raises(ValueError):
+        blk.computePriorities(n, steps, q_dev[:-1], 0.95)
 
 
 def test_transition_gather_rccl_single_rank_with_host_drain(T):
@@ -180,6 +355,7 @@ def test_transition_gather_rccl_single_rank_with_host_drain(T):
             for t in range(2):
                 gpu.perspectiveCounts()
                 gpu.actorStep(None, block=blk, slot=t)
+            blk.computePriorities(n, 2, None, 0.95)           # eps = 1: no Q-values, priority = |reward|
             slot = tg.gather(blk.buf)
             torch.cuda.synchronize()
             sent.append((slot, blk.buf.clone()))
@@ -189,6 +365,11 @@ def test_transition_gather_rccl_single_rank_with_host_drain(T):
             assert torch.equal(tg.slot_view(slot, 0, host=True), want.cpu())
         rec = wire.decode(tg.slot_view(sent[-1][0], 0, host=True).numpy(), d, 2 * n)
         assert rec["perspective"].shape == (2 * n, 2, d, d) and set(np.unique(rec["action"][:, 3])) <= {1, 2, 3}
+        # the priority arrives with its transition, bit-equal to what the device computed
+        want = blocks[(len(sent) - 1) & 1].unpack()["priority"].cpu().numpy()
+        records, prio = wire.to_records(rec, d)
+        assert np.array_equal(prio.view(np.uint32), want.view(np.uint32)) and np.array_equal(prio, np.abs(rec["reward"]))
+        assert records.shape[0] == 2 * n and prio.max() > 0
         gpu.close()
     finally:
         dist.destroy_process_group()

@@ -24,22 +24,55 @@ def make_transitions(d, n, seed):
     return per, nper, a2, rew.astype(np.float32), term
 
 
+def make_priorities(n, seed):
+    """f32 priorities with awkward bit patterns (denormal, large, exact integers)."""
+    rng = np.random.default_rng(1000 + seed)
+    p = np.abs(rng.standard_normal(n) * 10.0 ** rng.integers(-3, 3, n)).astype(np.float32)
+    p[::11] = np.float32(1e-40)
+    p[5::13] = 100.0
+    return p
+
+
 @pytest.mark.parametrize("d", (3, 5, 7, 9, 11))
 def test_wire_round_trip(d):
     n, cap = 37, 64
     per, nper, act, rew, term = make_transitions(d, n, 3)
-    buf = wire.encode(d, per, nper, act, rew, term, cap=cap)
+    prio = make_priorities(n, 3)
+    buf = wire.encode(d, per, nper, act, rew, term, cap=cap, priority=prio)
     assert buf.size == wire.block_bytes(d, cap)
     out = wire.decode(buf, d, cap, 0, n)
     assert np.array_equal(out["perspective"], per) and np.array_equal(out["next_perspective"], nper)
     assert np.array_equal(out["action"], act) and np.array_equal(out["reward"], rew)
     assert np.array_equal(out["terminal"], term)
+    assert np.array_equal(out["priority"].view(np.uint32), prio.view(np.uint32))   # bit-equal
+    assert np.array_equal(out["slot"], np.arange(n))
     part = wire.decode(buf, d, cap, 5, 9)
     assert np.array_equal(part["perspective"], per[5:14]) and np.array_equal(part["action"], act[5:14])
-    rec = wire.to_records(out, d)
+    assert np.array_equal(part["priority"], prio[5:14])
+    # the unused tail of the block (slots n..cap) holds no transitions: dropped by default
+    assert wire.decode(buf, d, cap)["perspective"].shape[0] == n
+    assert wire.decode(buf, d, cap, drop_empty=False)["perspective"].shape[0] == cap
+    rec, pr = wire.to_records(out, d)                        # the (transition, priority) pairs of IO_mp.py:60-66
+    assert rec.dtype == wire.transition_type(d)
     assert rec.dtype.itemsize == {3: 329, 5: 841, 7: 1609, 9: 2633, 11: 3913}[d]   # SURVEY A0
     assert np.array_equal(rec["action"]["position"][:, 1], np.full(n, d // 2))
-    assert wire.block_bytes(7, 1 << 16) == (1 << 16) * 41                          # 41 B / transition at d=7
+    assert pr.dtype == np.float32 and np.array_equal(pr, prio) and len(list(zip(rec, pr))) == n
+    assert wire.block_bytes(7, 1 << 16) == (1 << 16) * 45                          # 45 B / transition at d=7
+
+
+def test_empty_slots_are_dropped():
+    """A slot with action word 0 (op = 0: the lattice took no action that step) is not a transition."""
+    d, n = 5, 20
+    per, nper, act, rew, term = make_transitions(d, n, 4)
+    act = act.copy()
+    hole = np.array([0, 7, 19])
+    act[hole] = 0
+    buf = wire.encode(d, per, nper, act, rew, term, priority=make_priorities(n, 4))
+    out = wire.decode(buf, d, n)
+    keep = np.setdiff1d(np.arange(n), hole)
+    assert np.array_equal(out["slot"], keep) and np.array_equal(out["perspective"], per[keep])
+    rec, pr = wire.to_records(out, d)
+    assert rec.shape[0] == n - 3 and pr.shape[0] == n - 3 and (rec["action"]["op"] >= 1).all()
 
 
 def test_shard_ranges_cover_all_envs():
@@ -68,7 +101,8 @@ def _worker(rank, world, port, d, n, q):
         slots = []
         for flush in range(3):                              # three flushes through a 2-slot ring
             per, nper, act, rew, term = make_transitions(d, n, 10 * flush + rank)
-            buf = torch.from_numpy(wire.encode(d, per, nper, act, rew, term))
+            buf = torch.from_numpy(wire.encode(d, per, nper, act, rew, term,
+                                               priority=make_priorities(n, 10 * flush + rank)))
             slots.append(g.gather(buf))
         g.wait()
         ok = True
@@ -80,6 +114,11 @@ def _worker(rank, world, port, d, n, q):
                     out = wire.decode(g.slot_view(slot, r).numpy(), d, n)
                     ok &= np.array_equal(out["perspective"], per) and np.array_equal(out["next_perspective"], nper)
                     ok &= np.array_equal(out["action"], act) and np.array_equal(out["reward"], rew)
+                    # the priority travels in the same block and arrives bit-equal (Actor_mp.py:152, IO_mp.py:60-66)
+                    want = make_priorities(n, 10 * flush + r)
+                    ok &= np.array_equal(out["priority"].view(np.uint32), want.view(np.uint32))
+                    rec, pr = wire.to_records(out, d)
+                    ok &= rec.shape[0] == n and np.array_equal(pr, want)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

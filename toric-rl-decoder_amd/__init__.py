@@ -9,9 +9,10 @@ from ._lib import ToricEnvError, build, load, LIB_PATH  # noqa: F401
 from .envset import (EnvSet, ToricEnv, TransitionBlock, generatePerspectiveBatch,  # noqa: F401
                      generateTransitionParallel, make, to_structured, transition_dtype, SUPPORTED_SIZES)
 
-from .policy import NN_11, evaluate, predictMaxOptimized, segment_max, selectActionBatch  # noqa: F401,E402
+from .policy import (NN_11, evaluate, predictMaxOptimized, seed_select, segment_max, selectActionBatch,  # noqa: F401,E402
+                     selectActionEnvSet)
 
 from .actor import computePrioritiesParallel, run_actor  # noqa: F401,E402
 
-__all__ = ["computePrioritiesParallel", "run_actor", "NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "EnvSet", "ToricEnv", "TransitionBlock", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
+__all__ = ["computePrioritiesParallel", "run_actor", "NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "selectActionEnvSet", "seed_select", "EnvSet", "ToricEnv", "TransitionBlock", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
            "transition_dtype", "ToricEnvError", "build", "load", "LIB_PATH", "SUPPORTED_SIZES"]

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 TQ_F32, TQ_F16, TQ_BF16, TQ_U8 = 0, 1, 2, 3
 TQ_PERR_FIXED, TQ_PERR_LINEAR, TQ_PERR_RANDOM = 0, 1, 2
-TQ_E_INVALID, TQ_E_HIP, TQ_E_CAPACITY, TQ_E_ACTION = -1, -2, -3, -4
+TQ_E_INVALID, TQ_E_HIP, TQ_E_CAPACITY, TQ_E_ACTION, TQ_E_INDEX, TQ_E_RESET = -1, -2, -3, -4, -5, -6
 
 # every symbol include/toricenv.h declares: (name, restype, argtypes)
 _vp, _i, _i64, _u64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
@@ -38,15 +38,18 @@ SYMBOLS = [
     ("tq_is_terminal", _i, [_vp, _vp, _vp]),
     ("tq_persp_count", _i, [_vp, _vp, _vp, _vp]),
     ("tq_persp_write", _i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    ("tq_states_reserve", _i, [_i, _i]),
     ("tq_states_persp_count", _i, [_i, _i, _vp, _vp, _vp, _vp]),
     ("tq_states_persp_write", _i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     ("tq_select_action", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("tq_states_select_action", _i, [_i, _vp, _vp, _vp, _vp, _u64, _u64, _i64, _vp, _vp, _vp]),
     ("tq_states_check", _i, [_vp]),
     ("tq_segment_max", _i, [_vp, _vp, _i, _vp, _vp, _vp]),
     ("tq_transition_write", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("tq_states_transition", _i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("tq_transition_block_bytes", _i64, [_i, _i64]),
-    ("tq_transition_unpack", _i, [_i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("tq_transition_unpack", _i, [_i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("tq_block_priorities", _i, [_i, _vp, _i64, _i, _i, _vp, _d, _vp]),
     ("tq_actor_step", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     ("tq_check", _i, [_vp, _vp]),
 ]
@@ -90,6 +93,6 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().tq_last_error().decode("utf-8", "replace")
-        if rc in (TQ_E_INVALID, TQ_E_ACTION):
+        if rc in (TQ_E_INVALID, TQ_E_ACTION, TQ_E_INDEX):
             raise ValueError(f"libtoricenv: {msg}")
         raise ToricEnvError(f"libtoricenv error {rc}: {msg}")

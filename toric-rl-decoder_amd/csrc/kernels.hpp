@@ -25,7 +25,7 @@
 namespace tq {
 
 enum { PL_X0 = 0, PL_X1 = 1, PL_Z0 = 2, PL_Z1 = 3, PL_V = 4, PL_P = 5 };
-enum { ERR_ACTION = 1, ERR_CAPACITY = 2 };
+enum { ERR_ACTION = 1, ERR_CAPACITY = 2, ERR_RESET_DUP = 4, ERR_RESET_ROUNDS = 8, ERR_INDEX = 16 };
 
 template <int W>
 __device__ __forceinline__ Bits<W> load_plane(const uint64_t* __restrict__ planes, int plane, int64_t N, int64_t e) {
@@ -109,23 +109,34 @@ __device__ __forceinline__ void block_count_partial(int my_count, int64_t* __res
 
 // ------------------------------------------------------------------ reset
 // env.reset(p_error) per lattice (EnvSet.py:19-36).  idx == nullptr: all lattices.
+// Indexed mode: an index outside [0,N) latches ERR_INDEX; an index listed twice latches
+// ERR_RESET_DUP (mark[e] holds the epoch of the last indexed reset that touched lattice e, so the
+// second thread of a pair sees its own epoch) and only the first thread resets the lattice.  A
+// lattice whose syndrome is still empty after MAX_RESET_ROUNDS rounds (p_error ~ 0) latches
+// ERR_RESET_ROUNDS.
 template <int D>
 __global__ __launch_bounds__(256) void k_reset(uint64_t* __restrict__ planes, uint32_t* __restrict__ episodes,
                                                uint32_t* __restrict__ steps, int32_t* __restrict__ counts,
                                                const int32_t* __restrict__ idx, int n_idx,
                                                const double* __restrict__ p_err, double p_default,
                                                uint64_t seed, int64_t first_env, int64_t N,
-                                               int64_t* __restrict__ part256) {
+                                               int64_t* __restrict__ part256, uint32_t* __restrict__ mark,
+                                               uint32_t epoch, int* __restrict__ err) {
     using L = Lat<D>;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = idx ? n_idx : N;
     int64_t e = -1;
     if (t < m) e = idx ? idx[t] : t;
+    if (idx && t < m) {
+        if (e < 0 || e >= N) { atomicOr(err, ERR_INDEX); e = -1; }
+        else if (atomicExch(&mark[e], epoch) == epoch) { atomicOr(err, ERR_RESET_DUP); e = -1; }
+    }
     int cnt = 0;
     if (e >= 0 && e < N) {
         typename L::State s;
         const uint32_t ep = episodes[e];
         reset_lattice<D>(s, seed, (uint32_t)(first_env + e), ep, p_err ? p_err[t] : p_default);
+        if (!(s.v.any() || s.p.any())) atomicOr(err, ERR_RESET_ROUNDS);
         store_state<D>(planes, N, e, s);
         episodes[e] = ep + 1;
         steps[e] = 0;
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(256) void k_step(uint64_t* __restrict__ planes, uin
 // ------------------------------------------------------------------ packed transition block
 struct BlockView {     // SoA sections of a packed transition block (see include/toricenv.h)
     uint64_t* pv; uint64_t* pp; uint64_t* nv; uint64_t* np;
-    uint32_t* action; float* reward; uint8_t* terminal;
+    uint32_t* action; float* reward; float* priority; uint8_t* terminal;
     int64_t cap;
 };
 __host__ __device__ inline int64_t align8(int64_t x) { return (x + 7) & ~(int64_t)7; }
@@ -193,11 +204,12 @@ __host__ __device__ inline BlockView block_view(void* base, int W, int64_t cap) 
     b.np = (uint64_t*)p; p += 8 * (int64_t)W * cap;
     b.action = (uint32_t*)p; p += align8(4 * cap);
     b.reward = (float*)p; p += align8(4 * cap);
+    b.priority = (float*)p; p += align8(4 * cap);
     b.terminal = (uint8_t*)p;
     return b;
 }
 __host__ __device__ inline int64_t block_bytes(int W, int64_t cap) {
-    return 4 * 8 * (int64_t)W * cap + 2 * align8(4 * cap) + align8(cap);
+    return 4 * 8 * (int64_t)W * cap + 3 * align8(4 * cap) + align8(cap);
 }
 
 template <int D>
@@ -220,6 +232,21 @@ __device__ __forceinline__ void write_transition(const BlockView& b, int64_t slo
     b.terminal[slot] = (uint8_t)terminal;
 }
 
+// A slot without a transition (no-op or rejected action): action word 0 (op = 0 marks the slot
+// invalid for tq_transition_unpack / wire.decode), everything else zero -- never stale data.
+template <int D>
+__device__ __forceinline__ void write_empty_slot(const BlockView& b, int64_t slot) {
+    constexpr int W = Lat<D>::W;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        b.pv[(int64_t)k * b.cap + slot] = 0; b.pp[(int64_t)k * b.cap + slot] = 0;
+        b.nv[(int64_t)k * b.cap + slot] = 0; b.np[(int64_t)k * b.cap + slot] = 0;
+    }
+    b.action[slot] = 0u;
+    b.reward[slot] = 0.f;
+    b.terminal[slot] = 0;
+}
+
 // generateTransitionParallel for the last tq_step, into a packed block
 template <int D>
 __global__ __launch_bounds__(256) void k_transition(const uint64_t* __restrict__ planes, const uint64_t* __restrict__ prev,
@@ -230,7 +257,11 @@ __global__ __launch_bounds__(256) void k_transition(const uint64_t* __restrict__
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     const int4 a = reinterpret_cast<const int4*>(actions)[e];
-    if (!action_ok<D>(a.x, a.y, a.z, a.w)) { atomicOr(err, ERR_ACTION); return; }
+    if (!action_ok<D>(a.x, a.y, a.z, a.w)) {
+        if (!action_noop(a.w)) atomicOr(err, ERR_ACTION);
+        write_empty_slot<D>(b, slot_base + e);
+        return;
+    }
     const auto v0 = load_plane<W>(prev, 0, N, e), p0 = load_plane<W>(prev, 1, N, e);
     const auto v1 = load_plane<W>(planes, PL_V, N, e), p1 = load_plane<W>(planes, PL_P, N, e);
     write_transition<D>(b, slot_base + e, v0, p0, v1, p1, a.x, a.y, a.z, a.w, 0.f, 0);
@@ -317,8 +348,10 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
     st += 1;
     if (rewards && valid) rewards[e] = reward;
     if (terminals && valid) terminals[e] = (uint8_t)terminal;
-    if (has_block && ok && valid)
-        write_transition<D>(blk, slot_base + e, v0, p0, s.v, s.p, layer, row, col, op, reward, terminal);
+    if (has_block && valid) {                                // every slot is written, every step: no stale records
+        if (ok) write_transition<D>(blk, slot_base + e, v0, p0, s.v, s.p, layer, row, col, op, reward, terminal);
+        else write_empty_slot<D>(blk, slot_base + e);
+    }
     // reset policy of the caller (Actor_mp.py:171-183).  Few lanes of a wave reset in a given step, so
     // the lanes that do are served one after another by the whole wave (98 Philox draws in two passes
     // instead of a 98-iteration loop in one lane while 63 wait).
@@ -345,7 +378,10 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
         typename L::State fresh;
         reset_lattice_wave<D>(fresh, seed, (uint32_t)__shfl((int)env, src, 64), (uint32_t)__shfl((int)ep, src, 64),
                               __shfl(p, src, 64), lane);
-        if (lane == src) { s = fresh; ep += 1; st = 0; }
+        if (lane == src) {
+            if (!(fresh.v.any() || fresh.p.any())) atomicOr(err, ERR_RESET_ROUNDS);
+            s = fresh; ep += 1; st = 0;
+        }
     }
     const int cnt = valid ? L::persp_count(s.v, s.p) : 0;
     if (valid) {
@@ -457,7 +493,7 @@ template <int D>
 __global__ __launch_bounds__(256) void k_block_unpack(BlockView b, int64_t first, int64_t count,
                                                       uint8_t* __restrict__ persp, uint8_t* __restrict__ next_persp,
                                                       int32_t* __restrict__ actions, float* __restrict__ rewards,
-                                                      uint8_t* __restrict__ terminals) {
+                                                      uint8_t* __restrict__ terminals, float* __restrict__ priorities) {
     using L = Lat<D>;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count * L::NQ) return;
@@ -475,7 +511,35 @@ __global__ __launch_bounds__(256) void k_block_unpack(BlockView b, int64_t first
         }
         if (rewards) rewards[r] = b.reward[slot];
         if (terminals) terminals[r] = b.terminal[slot];
+        if (priorities) priorities[r] = b.priority[slot];
     }
+}
+
+// computePrioritiesParallel (util_actor.py:268-287) over a packed block that holds T steps of n
+// lattices in slot order t*n + e:  priority = | R + discount * max_a Q[t+1][e][a] - Q[t][e][op-1] |,
+// evaluated in f64 like the reference (its buffers are f64 arrays) and rounded once to f32.
+// q = f32[T+1][n][3] (the q_values selectActionBatch returned at each step, plus the step after the
+// last: local_buffer_Q and its np.roll, Actor_mp.py:146-150); q == nullptr reads as all zeros
+// (pure exploration).  Slots without a transition (op = 0) get priority 0.
+__global__ __launch_bounds__(256) void k_block_priorities(BlockView b, int64_t n, int64_t T, const float* __restrict__ q,
+                                                          double discount) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n * T) return;
+    const uint32_t a = b.action[s];
+    const int op = (int)(a >> 24);
+    float pr = 0.f;
+    if (op >= 1 && op <= 3) {
+        double qn = 0.0, qv = 0.0;
+        if (q) {
+            const float* nx = q + 3 * (s + n);                // row (t+1, e)
+            qn = (double)fmaxf(fmaxf(nx[0], nx[1]), nx[2]);
+            qv = (double)q[3 * s + (op - 1)];
+        }
+        const double m = discount * qn;
+        const double td = ((double)b.reward[s] + m) - qv;
+        pr = (float)fabs(td);
+    }
+    b.priority[s] = pr;
 }
 
 // ------------------------------------------------------------------ exclusive scan of counts
@@ -836,6 +900,7 @@ template <int D>
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ q, const int64_t* __restrict__ offsets,
                                                 const int32_t* __restrict__ pos, const double* __restrict__ eps,
                                                 const uint32_t* __restrict__ episodes, const uint32_t* __restrict__ steps,
+                                                uint32_t c1, uint32_t c2, uint32_t domain,
                                                 int32_t* __restrict__ actions, float* __restrict__ qv, uint64_t seed,
                                                 int64_t first_env, int64_t N) {
     const int lane = threadIdx.x & 63;
@@ -848,7 +913,8 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ q, con
         if (qv && lane < 3) qv[3 * e + lane] = 0.f;
         return;
     }
-    const U4 w = draw(seed, (uint32_t)(first_env + e), episodes[e], steps[e], DOMAIN_SEL, 0);
+    // handle-bound: counters = the lattice's (episode, step); stateless: the caller's call counter
+    const U4 w = draw(seed, (uint32_t)(first_env + e), episodes ? episodes[e] : c1, steps ? steps[e] : c2, domain, 0);
     const bool greedy = q != nullptr && (1.0 - eps[e]) > u01(w.x);
     int pidx, a;
     if (greedy) {

@@ -241,7 +241,7 @@ TQ_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     return U4{c0, c1, c2, c3};
 }
 
-enum : uint32_t { DOMAIN_ERR = 0, DOMAIN_SEL = 1, DOMAIN_PERR = 2 };
+enum : uint32_t { DOMAIN_ERR = 0, DOMAIN_SEL = 1, DOMAIN_PERR = 2, DOMAIN_SEL_CALL = 3 };
 constexpr int MAX_RESET_ROUNDS = 4096;
 
 TQ_HD U4 draw(uint64_t seed, uint32_t env, uint32_t episode, uint32_t round, uint32_t domain, uint32_t index) {

@@ -49,13 +49,30 @@ struct DeviceCtx {
     std::mutex mu;
     uint8_t* lut[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int* err = nullptr;             // error latch of the stateless entry points (tq_states_check)
-    void* ws = nullptr;             // scratch of the stateless entry points
+    void* ws = nullptr;             // scratch of the tq_states_persp_* entry points (tq_states_reserve)
     size_t ws_bytes = 0;
     int num_cus = 0;
 };
 DeviceCtx g_ctx[MAX_DEVICES];
 
 inline dim3 grid1(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// alignment contract of include/toricenv.h: the kernels use 16-byte vector accesses on these
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+#define REQUIRE_ALIGNED16(p, name)                                                        \
+    do {                                                                                  \
+        if ((p) && !aligned16(p)) return fail(TQ_E_INVALID, "%s must be 16-byte aligned", name); \
+    } while (0)
+
+int decode_latch(int flag) {
+    if (flag & tq::ERR_ACTION) return fail(TQ_E_ACTION, "an action outside the lattice or with op not in 1..3 was applied");
+    if (flag & tq::ERR_CAPACITY) return fail(TQ_E_CAPACITY, "perspective stack capacity exceeded");
+    if (flag & tq::ERR_INDEX) return fail(TQ_E_INDEX, "tq_reset_idx: an index outside [0, n_envs) was given");
+    if (flag & tq::ERR_RESET_DUP) return fail(TQ_E_INDEX, "tq_reset_idx: an index was listed more than once");
+    if (flag & tq::ERR_RESET_ROUNDS)
+        return fail(TQ_E_RESET, "a reset drew %d rounds without producing a defect (p_error too small)", tq::MAX_RESET_ROUNDS);
+    return TQ_OK;
+}
 
 #define DISPATCH_D(d, CALL)          \
     switch (d) {                     \
@@ -160,6 +177,9 @@ struct tq_env {
     bool partial_valid;    // left current by the last all-lattice kernel (false after tq_reset_idx)
     double* p_roof;
     int* err;              // device error latch
+    uint32_t* mark;        // [N] epoch of the last indexed reset that touched the lattice (duplicate detection)
+    uint32_t reset_epoch;
+    void* tblock;          // packed block of N slots: scratch of tq_transition_write
     const uint8_t* lut;
     int num_cus;
 };
@@ -173,9 +193,12 @@ struct DeviceGuard {
     bool switched = false;
     int enter(const tq_env* h) {
         if (!h) return fail(TQ_E_INVALID, "NULL handle");
+        return enter_device(h->device);
+    }
+    int enter_device(int device) {
         if (int rc = current_device(&prev)) return rc;
-        if (prev != h->device) {
-            HIPCHECK(hipSetDevice(h->device));
+        if (prev != device) {
+            HIPCHECK(hipSetDevice(device));
             switched = true;
         }
         return TQ_OK;
@@ -204,7 +227,8 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     HIPCHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev || device >= MAX_DEVICES)
         return fail(TQ_E_INVALID, "device %d not available (%d HIP devices)", device, ndev);
-    HIPCHECK(hipSetDevice(device));
+    DeviceGuard guard;                                        // the caller's current device is restored on return
+    if (int rc = guard.enter_device(device)) return rc;
     tq_env* h = new (std::nothrow) tq_env();
     if (!h) return fail(TQ_E_INVALID, "out of host memory");
     memset(h, 0, sizeof(*h));
@@ -223,6 +247,9 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc((void**)&h->partial, ((N + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8);
     alloc((void**)&h->p_roof, N * 8);
     alloc((void**)&h->err, 4);
+    alloc((void**)&h->mark, N * 4);
+    alloc(&h->tblock, (size_t)tq::block_bytes(h->w, n_envs));
+    h->reset_epoch = 0;
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
     h->num_cus = g_ctx[device].num_cus;
@@ -232,7 +259,9 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
 
 int tq_destroy(tq_env* h) {
     if (!h) return TQ_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard;
+    (void)guard.enter_device(h->device);
+    (void)hipFree(h->mark); (void)hipFree(h->tblock);
     (void)hipFree(h->planes); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
     (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->err);
     delete h;
@@ -241,7 +270,8 @@ int tq_destroy(tq_env* h) {
 
 int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int max_steps_per_episode) {
     if (!h) return fail(TQ_E_INVALID, "NULL handle");
-    if (!(p_error_default >= 0.0 && p_error_default <= 1.0)) return fail(TQ_E_INVALID, "p_error must be in [0,1]");
+    // p_error = 0 can never produce a defect: every reset would spin through MAX_RESET_ROUNDS rounds
+    if (!(p_error_default > 0.0 && p_error_default <= 1.0)) return fail(TQ_E_INVALID, "p_error must be in (0,1]");
     if (max_steps_per_episode < 1) return fail(TQ_E_INVALID, "max_steps_per_episode must be >= 1");
     h->sched.p_default = p_error_default;
     h->terminal_reward = terminal_reward;
@@ -253,6 +283,8 @@ int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_fin
     DeviceGuard guard;
     if (int rc = guard.enter(h)) return rc;
     if (strategy < TQ_PERR_FIXED || strategy > TQ_PERR_RANDOM) return fail(TQ_E_INVALID, "unknown p_error strategy %d", strategy);
+    if (!(p_start > 0.0 && p_start <= 1.0 && p_final > 0.0 && p_final <= 1.0 && p_delta >= 0.0))
+        return fail(TQ_E_INVALID, "p_error schedule needs 0 < p_start, p_final <= 1 and p_delta >= 0");
     h->sched.strategy = strategy; h->sched.p_start = p_start; h->sched.p_final = p_final; h->sched.p_delta = p_delta;
     // env_p_errors = ones * p_start (Actor_mp.py:46)
     double* host = new (std::nothrow) double[h->n];
@@ -271,7 +303,7 @@ int tq_reset_all(tq_env* h, const double* p_err, void* stream_) {
     HANDLE(h);
 #define CALL(D) hipLaunchKernelGGL(tq::k_reset<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->episodes, \
         h->steps, h->counts, (const int32_t*)nullptr, 0, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n, \
-        h->partial)
+        h->partial, h->mark, 0u, h->err)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
@@ -283,8 +315,13 @@ int tq_reset_idx(tq_env* h, const int32_t* idx, int n_idx, const double* p_err, 
     HANDLE(h);
     if (n_idx < 0 || (n_idx > 0 && !idx)) return fail(TQ_E_INVALID, "bad idx / n_idx");
     if (n_idx == 0) return TQ_OK;
+    if (++h->reset_epoch == 0) {                             // epoch 0 is the mark array's initial value
+        HIPCHECK(hipMemsetAsync(h->mark, 0, 4 * (size_t)h->n, stream));
+        h->reset_epoch = 1;
+    }
 #define CALL(D) hipLaunchKernelGGL(tq::k_reset<D>, grid1(n_idx, 256), dim3(256), 0, stream, h->planes, h->episodes, \
-        h->steps, h->counts, idx, n_idx, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n, (int64_t*)nullptr)
+        h->steps, h->counts, idx, n_idx, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n, (int64_t*)nullptr, \
+        h->mark, h->reset_epoch, h->err)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
@@ -295,6 +332,7 @@ int tq_reset_idx(tq_env* h, const int32_t* idx, int n_idx, const double* p_err, 
 int tq_step(tq_env* h, const int32_t* actions, float* rewards, uint8_t* terminals, void* stream_) {
     HANDLE(h);
     if (!actions) return fail(TQ_E_INVALID, "actions is NULL");
+    REQUIRE_ALIGNED16(actions, "actions");
 #define CALL(D) hipLaunchKernelGGL(tq::k_step<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->prev, actions, \
         rewards, terminals, h->steps, h->counts, (float)h->terminal_reward, (int64_t)h->n, h->err, h->partial)
     DISPATCH_D(h->d, CALL)
@@ -381,6 +419,8 @@ int tq_is_terminal(tq_env* h, uint8_t* out, void* stream_) {
 int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream_) {
     HANDLE(h);
     if (!offsets) return fail(TQ_E_INVALID, "offsets is NULL");
+    REQUIRE_ALIGNED16(offsets, "offsets");
+    REQUIRE_ALIGNED16(counts, "counts");
     if (int rc = launch_scan(h->counts, h->partial, h->partial_valid, offsets, counts, h->n, stream)) return rc;
     h->partial_valid = true;
     return TQ_OK;
@@ -391,6 +431,8 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
     HANDLE(h);
     if (!offsets || !out) return fail(TQ_E_INVALID, "offsets / out is NULL");
     if (capacity < 0) return fail(TQ_E_INVALID, "negative capacity");
+    REQUIRE_ALIGNED16(out, "out");
+    REQUIRE_ALIGNED16(positions, "positions");
     const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
 #define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->lut, h->err, stream)) return rc
     DISPATCH_D(h->d, CALL)
@@ -399,20 +441,42 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
 }
 
 // ---- stateless variants (states outside a handle) -------------------------------------------
-static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int** err) {
-    DeviceCtx& c = g_ctx[dev];
-    std::lock_guard<std::mutex> lock(c.mu);
+static size_t states_scratch_bytes(int d, int64_t n) {
     const size_t w = (size_t)(d * d + 63) / 64;
     const size_t cnt_bytes = (((size_t)n * 4 + 32 + 15) & ~(size_t)15);
     const size_t part_bytes = (((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8;
-    const size_t need = 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes;
+    return 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes;
+}
+
+// set-up call: allocates (and synchronises); the tq_states_persp_* calls themselves never allocate
+int tq_states_reserve(int d, int n_max) {
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (n_max <= 0) return fail(TQ_E_INVALID, "n_max must be > 0");
+    int dev;
+    if (int rc = current_device(&dev)) return rc;
+    const uint8_t* lut_unused;
+    if (int rc = get_lut(dev, d, nullptr, &lut_unused)) return rc;
+    DeviceCtx& c = g_ctx[dev];
+    std::lock_guard<std::mutex> lock(c.mu);
+    const size_t need = states_scratch_bytes(d, n_max);
     if (c.ws_bytes < need) {
+        HIPCHECK(hipDeviceSynchronize());                    // work queued on the old scratch must finish first
         if (c.ws) HIPCHECK(hipFree(c.ws));
         c.ws = nullptr; c.ws_bytes = 0;
         HIPCHECK(hipMalloc(&c.ws, need));
         HIPCHECK(hipMemset(c.ws, 0, need));
         c.ws_bytes = need;
     }
+    return TQ_OK;
+}
+
+static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int** err) {
+    DeviceCtx& c = g_ctx[dev];
+    std::lock_guard<std::mutex> lock(c.mu);
+    const size_t w = (size_t)(d * d + 63) / 64;
+    const size_t cnt_bytes = (((size_t)n * 4 + 32 + 15) & ~(size_t)15);
+    if (c.ws_bytes < states_scratch_bytes(d, n))
+        return fail(TQ_E_CAPACITY, "stateless scratch too small for %d states of d=%d: call tq_states_reserve(d, n_max) first", n, d);
     *vp = (uint64_t*)c.ws;
     *counts = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8);
     *partial = (int64_t*)((char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes);
@@ -424,6 +488,8 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
     hipStream_t stream = (hipStream_t)stream_;
     if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
     if (n <= 0 || !states || !offsets) return fail(TQ_E_INVALID, "bad n / states / offsets");
+    REQUIRE_ALIGNED16(offsets, "offsets");
+    REQUIRE_ALIGNED16(counts, "counts");
     int dev;
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut_unused;
@@ -443,6 +509,8 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     hipStream_t stream = (hipStream_t)stream_;
     if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
     if (n <= 0 || !states || !offsets || !out || capacity < 0) return fail(TQ_E_INVALID, "bad arguments");
+    REQUIRE_ALIGNED16(out, "out");
+    REQUIRE_ALIGNED16(positions, "positions");
     int dev;
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut;
@@ -464,6 +532,8 @@ int tq_states_transition(int d, int n, const uint8_t* states, const uint8_t* nex
     hipStream_t stream = (hipStream_t)stream_;
     if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
     if (n <= 0 || !actions || (persp && !states) || (next_persp && !next_states)) return fail(TQ_E_INVALID, "bad arguments");
+    REQUIRE_ALIGNED16(actions, "actions");
+    REQUIRE_ALIGNED16(actions_out, "actions_out");
     int dev;
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut;
@@ -488,9 +558,7 @@ int tq_states_check(void* stream_) {
     HIPCHECK(hipMemcpyAsync(&flag, latch, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHECK(hipStreamSynchronize(stream));
     if (flag) HIPCHECK(hipMemsetAsync(latch, 0, sizeof(int), stream));
-    if (flag & tq::ERR_ACTION) return fail(TQ_E_ACTION, "an action outside the lattice or with op not in 1..3 was applied");
-    if (flag & tq::ERR_CAPACITY) return fail(TQ_E_CAPACITY, "perspective stack capacity exceeded");
-    return TQ_OK;
+    return decode_latch(flag);
 }
 
 int tq_select_action(tq_env* h, const float* q_table, const int64_t* offsets, const int32_t* positions,
@@ -499,9 +567,26 @@ int tq_select_action(tq_env* h, const float* q_table, const int64_t* offsets, co
     if (!offsets || !positions || !actions) return fail(TQ_E_INVALID, "offsets / positions / actions is NULL");
     if (q_table && !eps) return fail(TQ_E_INVALID, "eps is NULL");
 #define CALL(D) hipLaunchKernelGGL(tq::k_select<D>, grid1((int64_t)h->n * 64, 256), dim3(256), 0, stream, q_table, offsets, \
-        positions, eps, h->episodes, h->steps, actions, q_values, h->seed, h->first_env, (int64_t)h->n)
+        positions, eps, h->episodes, h->steps, 0u, 0u, (uint32_t)tq::DOMAIN_SEL, actions, q_values, h->seed, h->first_env, \
+        (int64_t)h->n)
     DISPATCH_D(h->d, CALL)
 #undef CALL
+    KCHECK();
+    return TQ_OK;
+}
+
+int tq_states_select_action(int n, const float* q_table, const int64_t* offsets, const int32_t* positions,
+                            const double* eps, uint64_t seed, uint64_t call_counter, int64_t first_id,
+                            int32_t* actions, float* q_values, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n <= 0 || !offsets || !positions || !actions) return fail(TQ_E_INVALID, "bad n / offsets / positions / actions");
+    if (q_table && !eps) return fail(TQ_E_INVALID, "eps is NULL");
+    if (first_id < 0 || first_id + n > 0xFFFFFFFFll) return fail(TQ_E_INVALID, "state ids must fit in 32 bits");
+    // the kernel does not depend on the lattice size (positions carry the coordinates)
+    hipLaunchKernelGGL(tq::k_select<3>, grid1((int64_t)n * 64, 256), dim3(256), 0, stream, q_table, offsets, positions, eps,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)call_counter,
+                       (uint32_t)(call_counter >> 32), (uint32_t)tq::DOMAIN_SEL_CALL, actions, q_values, seed, first_id,
+                       (int64_t)n);
     KCHECK();
     return TQ_OK;
 }
@@ -521,43 +606,48 @@ int64_t tq_transition_block_bytes(int d, int64_t cap) {
     return tq::block_bytes((d * d + 63) / 64, cap);
 }
 
-// scratch block of the handle-less tq_transition_write path lives in the stateless workspace
+// the packed block this goes through is the handle's own scratch (allocated by tq_create)
 int tq_transition_write(tq_env* h, const int32_t* actions, uint8_t* persp, uint8_t* next_persp,
                         int32_t* actions_out, void* stream_) {
     HANDLE(h);
     if (!actions) return fail(TQ_E_INVALID, "actions is NULL");
-    DeviceCtx& c = g_ctx[h->device];
-    void* blk = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(c.mu);
-        const size_t need = (size_t)tq::block_bytes(h->w, h->n);
-        if (c.ws_bytes < need) {
-            if (c.ws) HIPCHECK(hipFree(c.ws));
-            c.ws = nullptr; c.ws_bytes = 0;
-            HIPCHECK(hipMalloc(&c.ws, need));
-            c.ws_bytes = need;
-        }
-        blk = c.ws;
-    }
-    tq::BlockView b = tq::block_view(blk, h->w, h->n);
+    REQUIRE_ALIGNED16(actions, "actions");
+    REQUIRE_ALIGNED16(actions_out, "actions_out");
+    tq::BlockView b = tq::block_view(h->tblock, h->w, h->n);
 #define CALL(D) hipLaunchKernelGGL(tq::k_transition<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->prev, actions, \
         b, (int64_t)0, (int64_t)h->n, h->err)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
-    return tq_transition_unpack(h->d, blk, h->n, 0, h->n, persp, next_persp, actions_out, nullptr, nullptr, stream_);
+    return tq_transition_unpack(h->d, h->tblock, h->n, 0, h->n, persp, next_persp, actions_out, nullptr, nullptr, nullptr,
+                                stream_);
+}
+
+int tq_block_priorities(int d, void* block, int64_t cap, int n_envs, int n_steps, const float* q_values,
+                        double discount, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!block || n_envs <= 0 || n_steps <= 0 || (int64_t)n_envs * n_steps > cap)
+        return fail(TQ_E_INVALID, "bad block / n_envs / n_steps (n_envs * n_steps must be <= cap)");
+    tq::BlockView b = tq::block_view(block, (d * d + 63) / 64, cap);
+    hipLaunchKernelGGL(tq::k_block_priorities, grid1((int64_t)n_envs * n_steps, 256), dim3(256), 0, stream, b,
+                       (int64_t)n_envs, (int64_t)n_steps, q_values, discount);
+    KCHECK();
+    return TQ_OK;
 }
 
 int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, int64_t count, uint8_t* persp,
-                         uint8_t* next_persp, int32_t* actions, float* rewards, uint8_t* terminals, void* stream_) {
+                         uint8_t* next_persp, int32_t* actions, float* rewards, uint8_t* terminals, float* priorities,
+                         void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
     if (!block || first < 0 || count < 0 || first + count > cap) return fail(TQ_E_INVALID, "bad block / slot range");
     if (count == 0) return TQ_OK;
+    REQUIRE_ALIGNED16(actions, "actions");
     tq::BlockView b = tq::block_view(const_cast<void*>(block), (d * d + 63) / 64, cap);
     const int64_t total = count * 2 * d * d;
 #define CALL(D) hipLaunchKernelGGL(tq::k_block_unpack<D>, grid1(total, 256), dim3(256), 0, stream, b, first, count, persp, \
-        next_persp, actions, rewards, terminals)
+        next_persp, actions, rewards, terminals, priorities)
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
@@ -567,6 +657,9 @@ int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, i
 int tq_actor_step(tq_env* h, const int32_t* actions, int32_t* actions_out, float* rewards, uint8_t* terminals,
                   void* block, int64_t block_cap, int64_t slot_base, void* stream_) {
     HANDLE(h);
+    REQUIRE_ALIGNED16(actions, "actions");
+    REQUIRE_ALIGNED16(actions_out, "actions_out");
+    if (block && (reinterpret_cast<uintptr_t>(block) & 7u)) return fail(TQ_E_INVALID, "block must be 8-byte aligned");
     tq::BlockView b;
     memset(&b, 0, sizeof(b));
     if (block) {
@@ -589,9 +682,7 @@ int tq_check(tq_env* h, void* stream_) {
     HIPCHECK(hipMemcpyAsync(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHECK(hipStreamSynchronize(stream));
     if (flag) HIPCHECK(hipMemsetAsync(h->err, 0, sizeof(int), stream));
-    if (flag & tq::ERR_ACTION) return fail(TQ_E_ACTION, "an action outside the lattice or with op not in 1..3 was applied");
-    if (flag & tq::ERR_CAPACITY) return fail(TQ_E_CAPACITY, "perspective stack capacity exceeded");
-    return TQ_OK;
+    return decode_latch(flag);
 }
 
 }  // extern "C"

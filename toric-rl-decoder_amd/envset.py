@@ -135,7 +135,8 @@ class TransitionBlock:
 
     def unpack(self, first=0, count=None, buf=None):
         """-> dict of device tensors (perspective u8, next_perspective u8, action i32[n,4],
-        reward f32, terminal u8) for slots [first, first+count)."""
+        reward f32, terminal u8, priority f32) for slots [first, first+count).  Slots without a
+        transition have action op 0 (include/toricenv.h)."""
         buf = self.buf if buf is None else buf
         count = self.capacity - first if count is None else int(count)
         d, dev = self.d, buf.device
@@ -143,13 +144,27 @@ class TransitionBlock:
                    next_perspective=torch.empty((count, 2, d, d), dtype=torch.uint8, device=dev),
                    action=torch.empty((count, 4), dtype=torch.int32, device=dev),
                    reward=torch.empty(count, dtype=torch.float32, device=dev),
-                   terminal=torch.empty(count, dtype=torch.uint8, device=dev))
+                   terminal=torch.empty(count, dtype=torch.uint8, device=dev),
+                   priority=torch.empty(count, dtype=torch.float32, device=dev))
         with torch.cuda.device(dev):
             check(_lib.load().tq_transition_unpack(d, _ptr(buf), self.capacity, int(first), count,
                                                    _ptr(out["perspective"]), _ptr(out["next_perspective"]),
                                                    _ptr(out["action"]), _ptr(out["reward"]),
-                                                   _ptr(out["terminal"]), _stream()))
+                                                   _ptr(out["terminal"]), _ptr(out["priority"]), _stream()))
         return out
+
+    def computePriorities(self, no_envs, steps, q_values=None, discount=0.95):
+        """computePrioritiesParallel (util_actor.py:268-287) into the block's priority section for
+        the ``steps`` steps of ``no_envs`` lattices it holds (slot t*no_envs + e).  ``q_values``:
+        device f32 (steps+1, no_envs, 3) -- the q_values of every step plus the step after -- or
+        None for all-zero Q (pure exploration).  No synchronisation."""
+        if q_values is not None:
+            if (q_values.dtype != torch.float32 or not q_values.is_contiguous()
+                    or q_values.numel() != (int(steps) + 1) * int(no_envs) * 3 or q_values.device != self.buf.device):
+                raise ValueError("q_values must be a contiguous float32 device tensor of shape (steps+1, no_envs, 3)")
+        with torch.cuda.device(self.buf.device):
+            check(_lib.load().tq_block_priorities(self.d, _ptr(self.buf), self.capacity, int(no_envs), int(steps),
+                                                  _ptr(q_values), float(discount), _stream()))
 
 
 def transition_dtype(size):
@@ -271,6 +286,7 @@ class EnvSet:
                 raise ValueError("idx must be distinct env indices in range")
         out = torch.empty((k, 2, self.size, self.size), dtype=torch.uint8, device=self.device)
         if k:
+            # the device checks idx as well (range, duplicates) and latches TQ_E_INDEX for check()
             self._call(self._L.tq_reset_idx, _ptr(idx_t), k, _ptr(p))
             self._call(self._L.tq_get_state_idx, _ptr(idx_t), k, _ptr(out))
         return out.cpu().numpy().astype(np.float64) if self.numpy_io else out
@@ -351,10 +367,16 @@ class EnvSet:
         self._call(self._L.tq_persp_write, _ptr(off), _ptr(out), _ptr(positions), cap, _DTYPES[out.dtype])
         self._positions = positions
 
-    def generatePerspective(self, dtype=torch.float32):
-        """generatePerspectiveBatch + concatenate for the current states
-        (numba/util_actor.py:33-39,56-67) -> (perspectives (P,2,d,d), positions (P,3), counts (N,)).
+    def generatePerspective(self, states=None, dtype=torch.float32):
+        """generatePerspectiveBatch + concatenate (numba/util_actor.py:33-39,56-67) for the current
+        states, or for an explicit ``states`` array (n,2,d,d) like the reference's function
+        -> (perspectives (P,2,d,d), positions (P,3), counts (N,)).
         Reads P back from the device (one 8-byte copy), like the reference's data-dependent shape."""
+        if states is not None:
+            out, pos, counts = generatePerspectiveBatch(self.size // 2, self.size, states, dtype=dtype, device=self.device)
+            if self.numpy_io:
+                return out.cpu().numpy(), pos.cpu().numpy().astype(np.int64), counts.cpu().numpy().astype(np.int64)
+            return out, pos, counts
         counts, offsets = self.perspectiveCounts()
         P = int(offsets[-1].item())
         d = self.size
@@ -423,6 +445,19 @@ class EnvSet:
         return self._actions, self._rewards, self._terminals
 
 
+_reserved = {}      # (device index, d) -> states the device's stateless scratch is sized for
+
+
+def _reserve_states(dev, d, n):
+    """tq_states_reserve is a set-up call (allocates, synchronises): issue it only when a larger
+    batch than ever before arrives on this device; the tq_states_* calls themselves never allocate."""
+    key = (dev.index, d)
+    if _reserved.get(key, 0) < n:
+        with torch.cuda.device(dev):
+            check(_lib.load().tq_states_reserve(d, n))
+        _reserved[key] = n                                # the scratch only ever grows
+
+
 def generatePerspectiveBatch(grid_shift, toric_size, states, dtype=torch.float32, device=None):
     """numba/util_actor.py:56-67 for syndromes that do not live in an EnvSet (e.g. the learner's
     next_state batch, util_learner.py:48-111).  states: (n,2,d,d) numpy / tensor.
@@ -436,6 +471,7 @@ def generatePerspectiveBatch(grid_shift, toric_size, states, dtype=torch.float32
     n, d = int(st.shape[0]), int(toric_size)
     counts = torch.empty(n, dtype=torch.int32, device=dev)
     offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    _reserve_states(dev, d, n)
     with torch.cuda.device(dev):
         check(L.tq_states_persp_count(d, n, _ptr(st), _ptr(counts), _ptr(offsets), _stream()))
         P = int(offsets[-1].item())

@@ -51,10 +51,10 @@ def _forward_chunked(model, persp, chunk):
     return torch.cat(outs, dim=0)
 
 
-def selectActionBatch(envs, model, epsilon, dtype=torch.float32, chunk=1 << 16):
-    """selectActionBatch(number_of_actions, epsilon, grid_shift, toric_size, state, model, device)
-    of the reference for the lattices of ``envs`` (an EnvSet), everything on the device:
-    perspectives -> model forward (in chunks) -> epsilon-greedy selection.
+def selectActionEnvSet(envs, model, epsilon, dtype=torch.float32, chunk=1 << 16):
+    """The reference's selectActionBatch for the lattices that live in ``envs`` (an EnvSet), everything
+    on the device: perspectives -> model forward (in chunks) -> epsilon-greedy selection keyed by each
+    lattice's own (episode, step) counters.
     -> (actions (N,4), q_values (N,3)); numpy with envs.numpy_io, device tensors otherwise."""
     model.eval()
     io = envs.numpy_io
@@ -68,6 +68,48 @@ def selectActionBatch(envs, model, epsilon, dtype=torch.float32, chunk=1 << 16):
     if io:
         return act.cpu().numpy().astype(np.int64), qv.cpu().numpy()
     return act, qv
+
+
+# The reference's selectActionBatch draws from numpy's global RNG, which nothing ever seeds
+# (numba/util_actor.py:49,97-98).  Here the draws are Philox keyed (seed, state index, call number):
+# seed_select() fixes the stream; every selectActionBatch call advances the call number.
+_select_rng = {"seed": 0, "calls": 0}
+
+
+def seed_select(seed, calls=0):
+    _select_rng["seed"] = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _select_rng["calls"] = int(calls)
+
+
+def selectActionBatch(number_of_actions, epsilon, grid_shift, toric_size, state, model, device, chunk=1 << 16):
+    """Drop-in for src/numba/util_actor.py:11-53 -- same argument names, order and return types:
+    ``state`` (N,2,d,d) numpy array (or tensor), ``epsilon`` scalar or (N,) array, ``device`` the
+    ROCm device the model lives on -> (actions (N,4) int64 numpy, q_values (N,3) float64 numpy).
+    Perspective generation, the model forward and the epsilon-greedy selection (greedy iff
+    (1-eps) > U; first maximum in row-major order, :93-95; otherwise a uniform perspective and op,
+    :97-98) all run on the device; only the (N,4) / (N,3) results come back.  A state without defects
+    (the reference would raise on it, :93) gets action op 0 and zero q_values."""
+    if int(number_of_actions) != 3:
+        raise ValueError("number_of_actions must be 3 (env.action_space.high[-1], Actor_mp.py:58)")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError("device must be a cuda (ROCm) device: the toric env has no CPU path")
+    model.eval()
+    persp, pos, counts = generatePerspectiveBatch(grid_shift, toric_size, state, device=dev)
+    dev = persp.device
+    n = int(counts.numel())
+    offsets = torch.zeros(n + 2, dtype=torch.int64, device=dev)[:n + 1]
+    torch.cumsum(counts, 0, out=offsets[1:])
+    q = _forward_chunked(model, persp, chunk)
+    eps = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(np.asarray(epsilon, np.float64), (n,))), device=dev)
+    actions = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    qv = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    call = _select_rng["calls"]
+    _select_rng["calls"] = call + 1
+    with torch.cuda.device(dev):
+        check(_lib.load().tq_states_select_action(n, _ptr(q), _ptr(offsets), _ptr(pos), _ptr(eps),
+                                                  _select_rng["seed"], call, 0, _ptr(actions), _ptr(qv), _stream()))
+    return actions.cpu().numpy().astype(np.int64), qv.cpu().numpy().astype(np.float64)
 
 
 def segment_max(q_table, offsets, largest=None):
@@ -119,7 +161,7 @@ def evaluate(model, env, env_config, grid_shift, device, prediction_list_p_error
         q_sum = torch.zeros((), dtype=torch.float64, device=envs.device)
         q_cnt = torch.zeros((), dtype=torch.int64, device=envs.device)
         for _ in range(int(num_of_steps)):
-            act, qv = selectActionBatch(envs, model, epsilon, chunk=chunk)     # op 0 for solved lattices
+            act, qv = selectActionEnvSet(envs, model, epsilon, chunk=chunk)    # op 0 for solved lattices
             live = ~done
             chosen = torch.gather(qv, 1, (act[:, 3].long() - 1).clamp(min=0).unsqueeze(1)).squeeze(1)
             q_sum += (chosen.double() * live).sum()

@@ -419,6 +419,31 @@ def compute_priorities(A, R, Q, Qns, discount):
     return np.absolute(R + discount * qns_max - qv)
 
 
+def predict_max(q_fn, states):
+    """predictMaxOptimized (util_learner.py:48-111): the max Q-value of every state.  Quirks kept:
+    a state without perspectives (terminal) contributes one all-zero dummy perspective (:74-76) and
+    its output is forced to 0 (:108); every Q-slice is padded with zero rows up to the longest
+    slice before the argmax (:98-100), so a shorter slice yields max(max_q, 0).
+    ``q_fn(perspectives (P,2,d,d) float32) -> (P,3) float32``.  -> float32 (n,)."""
+    states = np.asarray(states)
+    n, d = states.shape[0], states.shape[-1]
+    per, _, cnt, off = generate_perspective_batch(states.astype(np.uint8))
+    chunks, lengths = [], []
+    for i in range(n):
+        p = per[off[i]:off[i + 1]] if cnt[i] else np.zeros((1, 2, d, d), per.dtype)
+        chunks.append(p)
+        lengths.append(p.shape[0])
+    q = np.asarray(q_fn(np.concatenate(chunks).astype(np.float32)), np.float32)
+    largest = max(lengths)
+    out = np.zeros(n, np.float32)
+    lo = 0
+    for i, m in enumerate(lengths):
+        padded = np.concatenate((q[lo:lo + m], np.zeros((largest - m, 3), np.float32)), axis=0)
+        out[i] = 0.0 if cnt[i] == 0 else padded.reshape(-1).max()
+        lo += m
+    return out
+
+
 def perror_schedule(seed, env_ids, episodes, p_start, p_roof, strategy):
     """Actor_mp.py:176-180: 'random' -> U(start, roof) else roof (linear)."""
     p_roof = np.asarray(p_roof, np.float64)

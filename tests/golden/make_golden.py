@@ -6,9 +6,12 @@ test-suite only read the resulting ``*.npz`` files (plain uint8/int/f32 arrays,
 loaded with allow_pickle=False).
 
 What is imported from the reference (numpy half of the path, importable here):
-  src/util.py        generatePerspective, generatePerspectiveOptimized,
-                     rotate_state, shift_state
-  src/util_actor.py  generateTransitionParallel, selectActionParallel_prime
+  src/util.py          generatePerspective, generatePerspectiveOptimized,
+                       rotate_state, shift_state
+  src/util_actor.py    generateTransitionParallel, selectActionParallel_prime,
+                       computePrioritiesParallel
+  src/util_learner.py  predictMaxOptimized (driven with an integer-weight linear model, so
+                       its fp32 Q-values are exact and the expected maxima are bit-exact)
 The only shim is restoring the numpy-1 aliases np.int/np.bool/np.float that
 numpy 2 removed (src/util.py:10 uses np.int).  ``src/numba/*`` needs numba, which
 is absent here and stays absent: those files restate src/util.py (the reference's
@@ -42,8 +45,10 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
 
+import torch                     # noqa: E402
 import src.util as RU            # noqa: E402  (reference)
 import src.util_actor as RA      # noqa: E402  (reference)
+import src.util_learner as RL    # noqa: E402  (reference)
 from oracle import toric_oracle as O  # noqa: E402
 
 
@@ -84,12 +89,53 @@ def ref_perspectives(d, states):
             np.asarray(poss, np.int64).reshape(P, 3), np.asarray(counts, np.int64))
 
 
+class IntLinearQ(torch.nn.Module):
+    """Q(perspective) = flatten(perspective) @ w with small integer weights: every product and sum
+    is an exact fp32 integer on any device, so the reference's maxima are reproducible bit-for-bit."""
+
+    def __init__(self, w):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.as_tensor(w, dtype=torch.float32), requires_grad=False)
+
+    def forward(self, x):
+        return x.flatten(1).float() @ self.w
+
+
+def learner_and_priority_vectors(d, rng):
+    """predictMaxOptimized (util_learner.py:48-111) and computePrioritiesParallel
+    (util_actor.py:268-287) run from the reference, inputs and outputs frozen."""
+    gs = int(d / 2)
+    n = 48
+    _, st = O.reset_lattices(int(rng.integers(1 << 30)), np.arange(n), 0, 0.08, d)
+    st[::7] = 0                                              # terminal states (dummy perspective, output 0)
+    st[1] = 0
+    st[1, 0, 0, 0] = st[1, 0, 1, 0] = 1                      # a short slice next to long ones: zero-padding quirk
+    w = rng.integers(-2, 3, (2 * d * d, 3)).astype(np.float32)
+    w[:, :] -= 1.0                                           # mostly negative Q: padding with zero rows matters
+    model = IntLinearQ(w)
+    batch_state = [torch.from_numpy(x.astype(np.float32)) for x in st]
+    out = RL.predictMaxOptimized(model, batch_state, gs, d, 'cpu').numpy().astype(np.float32)
+    # priorities: the shapes and dtypes of the actor's local buffers (Actor_mp.py:65-70,146-150)
+    N, T = 24, 5
+    A = np.stack((rng.integers(0, 2, (N, T)), rng.integers(0, d, (N, T)), rng.integers(0, d, (N, T)),
+                  rng.integers(1, 4, (N, T))), axis=2).astype(np.int64)
+    Q = np.empty((N, T + 1), dtype=(np.float64, 3))
+    Q[:] = (rng.standard_normal((N, T + 1, 3)) * 40).astype(np.float32)        # f32 network outputs in an f64 buffer
+    R = rng.integers(-4, 5, (N, T + 1)).astype(np.float64)
+    R[rng.random((N, T + 1)) < 0.15] = 100.0
+    pr = RA.computePrioritiesParallel(A, R[:, :-1], Q[:, :-1], np.roll(Q, -1, axis=1)[:, :-1], 0.95)
+    assert pr.dtype == np.float64 and np.array_equal(pr, O.compute_priorities(A, R[:, :-1], Q[:, :-1],
+                                                                               np.roll(Q, -1, axis=1)[:, :-1], 0.95))
+    return dict(pm_states=st.astype(np.uint8), pm_w=w, pm_out=out, pr_A=A.astype(np.uint8), pr_R=R[:, :-1],
+                pr_Q=Q.astype(np.float32), pr_discount=np.float64(0.95), pr_out=pr)
+
+
 def main():
     rng = np.random.default_rng(20200318)
     report = []
-    for d in (3, 5, 7, 9):
+    for d in (3, 5, 7, 9, 11):        # 11 last: the draws of the d <= 9 files are unchanged
         gs = int(d / 2)
-        k = {3: 40, 5: 30, 7: 24, 9: 16}[d]
+        k = {3: 40, 5: 30, 7: 24, 9: 16, 11: 8}[d]
         states = random_states(rng, d, k)
         n = states.shape[0]
 
@@ -142,6 +188,9 @@ def main():
         ract, rqv = RA.selectActionParallel_prime(qs, ps, np.ones(len(qs), bool))
         oact, oqv, _ = O.select_action_batch(q, offs, rpos, 0.0, 1, np.arange(n), 1, 0)
         assert np.array_equal(ract, oact[nz]) and np.array_equal(rqv.astype(np.float32), oqv[nz])
+
+        np.savez_compressed(os.path.join(HERE, f"learner_d{d}.npz"),
+                            **learner_and_priority_vectors(d, np.random.default_rng(7000 + d)))
 
         np.savez_compressed(
             os.path.join(HERE, f"reference_d{d}.npz"),

@@ -112,7 +112,7 @@ def test_config2_4096_envs_d5_bit_exact(T):
 
 
 # ------------------------------------------------------------------ reference golden vectors on the GPU
-@pytest.mark.parametrize("d", (3, 5, 7, 9))
+@pytest.mark.parametrize("d", (3, 5, 7, 9, 11))
 def test_golden_reference_vectors(T, golden_dir, d):
     g = np.load(os.path.join(golden_dir, f"reference_d{d}.npz"), allow_pickle=False)
     per, pos, cnt = T.generatePerspectiveBatch(d // 2, d, g["states"], dtype=torch.float32)

@@ -81,6 +81,37 @@ def test_predict_max_optimized(T, d):
     assert np.array_equal(plain, ref)
 
 
+@pytest.mark.parametrize("d", (3, 5, 7, 9, 11))
+def test_learner_goldens_from_the_reference(T, golden_dir, d):
+    """predictMaxOptimized and computePrioritiesParallel against vectors produced by running the
+    reference's own functions (tests/golden/make_golden.py): the device path, the numpy drop-in and
+    the packed-block kernel."""
+    import os
+    from toric_rl_decoder_amd import wire
+    g = np.load(os.path.join(golden_dir, f"learner_d{d}.npz"), allow_pickle=False)
+
+    class Lin(torch.nn.Module):
+        def __init__(self, w):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.as_tensor(w), requires_grad=False)
+
+        def forward(self, x):
+            return x.flatten(1).float() @ self.w
+
+    got = T.predictMaxOptimized(Lin(g["pm_w"]).cuda(), g["pm_states"], d // 2, d, "cuda").cpu().numpy()
+    assert np.array_equal(got, g["pm_out"])
+    A, R, Q, disc = g["pr_A"].astype(np.int64), g["pr_R"], g["pr_Q"].astype(np.float64), float(g["pr_discount"])
+    pr = T.computePrioritiesParallel(A, R, Q[:, :-1], np.roll(Q, -1, axis=1)[:, :-1], disc)
+    assert pr.dtype == np.float64 and np.array_equal(pr, g["pr_out"])
+    n, steps = A.shape[0], A.shape[1]
+    zeros = np.zeros((n * steps, 2, d, d), np.uint8)
+    buf = wire.encode(d, zeros, zeros, A.transpose(1, 0, 2).reshape(-1, 4), R.T.reshape(-1), np.zeros(n * steps, bool))
+    blk = T.TransitionBlock(d, n * steps, torch.device("cuda"))
+    blk.buf.copy_(torch.as_tensor(buf, device="cuda"))
+    blk.computePriorities(n, steps, torch.as_tensor(g["pr_Q"].transpose(1, 0, 2).copy(), device="cuda"), disc)
+    assert np.array_equal(blk.unpack()["priority"].cpu().numpy(), g["pr_out"].T.reshape(-1).astype(np.float32))
+
+
 def test_evaluate_matches_oracle_loop(T):
     """evaluation.py:10-124, episodes batched; compared with the same loop on the oracle."""
     d, episodes, max_steps = 5, 400, 12
@@ -301,7 +332,7 @@ def test_compute_priorities_numpy_and_block_kernel(T):
     d, n, steps = 7, 333, 5
     A = np.stack((rng.integers(0, 2, (n, steps)), rng.integers(0, d, (n, steps)), rng.integers(0, d, (n, steps)),
                   rng.integers(1, 4, (n, steps))), axis=2)
-    Qall = rng.standard_normal((n, steps + 1, 3)).astype(np.float32).astype(np.float64) * 50
+    Qall = (rng.standard_normal((n, steps + 1, 3)) * 50).astype(np.float32).astype(np.float64)   # f32 values, as the NN gives
     R = rng.integers(-4, 5, (n, steps)).astype(np.float64)
     R[rng.random((n, steps)) < 0.1] = 100.0
     want = O.compute_priorities(A, R, Qall[:, :-1], Qall[:, 1:], 0.95)

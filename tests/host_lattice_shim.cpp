@@ -119,7 +119,51 @@ static void t_step(int n, uint8_t* q, const int32_t* act, uint8_t* st, int32_t* 
     }                                      \
     return 0;
 
+// The perspective stack of each lattice through the bitstream algebra the stack-write kernel uses
+// (PStream): rotated planes, row-rolled table, masked column rolls, emit into the stream, window
+// reads back -- every lane's work done serially here.  out: u8 (P,2,d,d) at offsets[e]*NQ.
+template <int D>
+static void t_stream_stack(int n, const uint8_t* st, const int64_t* offsets, uint8_t* out) {
+    using L = Lat<D>;
+    using S = PStream<D>;
+    using B = typename L::B;
+    static uint32_t bits[S::MAX_DW];
+    for (int e = 0; e < n; ++e) {
+        B v, p, e0, e1, rv, rp;
+        pack_state<D>(st + (size_t)e * L::NQ, v, p);
+        L::hit_masks(v, p, e0, e1);
+        const int n0 = e0.popc(), cnt = n0 + e1.popc();
+        S::rotate_planes(v, p, rv, rp);
+        B rr[4][D], low[D];
+        for (int k = 0; k < D; ++k) {
+            rr[0][k] = L::roll_rows(v, k); rr[1][k] = L::roll_rows(p, k);
+            rr[2][k] = L::roll_rows(rv, k); rr[3][k] = L::roll_rows(rp, k);
+            low[k] = L::lowcols(k);
+        }
+        const int nd = (cnt * L::NQ + 31) / 32 + 2;
+        for (int i = 0; i < nd; ++i) bits[i] = 0;
+        int pidx = 0;
+        for (int l = 0; l < 2; ++l)
+            for (int c = 0; c < L::DD; ++c) {
+                if (!(l ? e1.get(c) : e0.get(c))) continue;
+                int rs, cs;
+                S::hit_shifts(l, c / D, c % D, rs, cs);
+                const B ov = S::roll_cols_masked(rr[2 * l][rs], cs, low[cs]);
+                const B op = S::roll_cols_masked(rr[2 * l + 1][rs], cs, low[cs]);
+                S::emit(pidx, ov, op, [&](int idx, uint32_t val) { bits[idx] |= val; });
+                ++pidx;
+            }
+        uint8_t* o = out + (size_t)offsets[e] * L::NQ;
+        for (uint32_t rel = 0; rel < (uint32_t)(cnt * L::NQ); ++rel) o[rel] = (uint8_t)(S::window(bits, rel) & 1u);
+    }
+}
+
 extern "C" {
+int shim_stream_stack(int d, int n, const uint8_t* st, const int64_t* offsets, uint8_t* out) {
+#define C_(D) t_stream_stack<D>(n, st, offsets, out)
+    DISPATCH(d, C_)
+#undef C_
+}
 int shim_syndrome(int d, int n, const uint8_t* q, uint8_t* st) {
 #define C_(D) t_syndrome<D>(n, q, st)
     DISPATCH(d, C_)

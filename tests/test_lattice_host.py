@@ -64,6 +64,25 @@ def test_bitplane_algebra(shim, d):
 
 
 @pytest.mark.parametrize("d", SIZES)
+def test_perspective_bitstream_algebra(shim, d):
+    """PStream (the stack-write kernel's algebra: rotate once, roll rows from a table, masked column
+    rolls, OR into the lattice's bit string, window reads) reproduces the oracle's stack bit for bit,
+    for sparse, dense, empty and full syndromes."""
+    rng = np.random.default_rng(200 + d)
+    n = 120
+    _, st = O.reset_lattices(3, np.arange(n), 0, 0.12, d)
+    st[40:80] = (rng.random((40, 2, d, d)) < 0.5)
+    st[80] = 0
+    st[81] = 1
+    st[82] = 0
+    st[82, 1, d - 1, d - 1] = 1
+    per, pos, cnt, off = O.generate_perspective_batch(st)
+    out = np.zeros_like(per)
+    assert shim.shim_stream_stack(d, n, P(st), P(off), P(out)) == 0
+    assert np.array_equal(out, per)
+
+
+@pytest.mark.parametrize("d", SIZES)
 def test_reset_matches_oracle(shim, d):
     rng = np.random.default_rng(100 + d)
     n = 300

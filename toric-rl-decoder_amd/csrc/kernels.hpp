@@ -644,7 +644,8 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// (hit, cell) -> source cell table, u8[NQ][NQ] (NQ <= 255 for d <= 11): filled once per handle.
+// (hit, cell) -> source cell table, u8[NQ][NQ] (NQ <= 255 for d <= 11): filled once per handle; used by
+// k_states_transition (the stack write needs no table any more).
 template <int D>
 __global__ void k_build_lut(uint8_t* __restrict__ lut) {
     using L = Lat<D>;
@@ -656,28 +657,69 @@ __global__ void k_build_lut(uint8_t* __restrict__ lut) {
     lut[t] = (uint8_t)L::persp_src(layer, i, j, c, r, s);
 }
 
+// Per-wave LDS of the stack write: the lattice's perspective bitstream (lattice.hpp, PStream) and the
+// small tables it is built from.
+template <int D>
+struct PerspLds {
+    using S = PStream<D>;
+    static constexpr int BITS_DW = (S::MAX_DW + 3) & ~3;
+    static constexpr int NQP = (Lat<D>::NQ + 7) & ~7;
+    __attribute__((aligned(16))) uint32_t bits[BITS_DW];       // bit pidx*NQ + cell = element `cell` of perspective pidx
+    uint64_t rr[4][D][Lat<D>::W];                              // V, P, rot V, rot P rolled by every row amount
+    uint64_t low[D][Lat<D>::W];                                // lowcols(k): destination columns [0,k) of a column roll
+    uint8_t hits[NQP];                                         // k-th hit -> flat qubit index
+};
+
+// `VEC` stream bits -> the four dwords of one 16-byte lane store
+template <typename OutT>
+__device__ __forceinline__ u32x4 expand_bits(uint32_t wb) {
+    using Enc = OutEnc<OutT>;
+    u32x4 r;
+    if (Enc::BITS == 32) {                                   // 4 bits -> 4 floats: sign-extended bit & 1.0f
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (uint32_t)(((int32_t)(wb << (31 - k))) >> 31) & Enc::ONE;
+    } else if (Enc::BITS == 16) {                            // 8 bits -> 4 x (2 halves): spread two bits, 24-bit multiply by ONE
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t t2 = (wb >> (2 * k)) & 3u;
+            r[k] = __umul24((t2 | (t2 << 15)) & 0x00010001u, Enc::ONE);
+        }
+    } else {                                                 // 16 bits -> 4 x (4 bytes): bit i of a nibble to byte i
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = __umul24((wb >> (4 * k)) & 15u, 0x00204081u) & 0x01010101u;
+    }
+    return r;
+}
+
 // vp = V/P planes: V word k of lattice e at vp[(0*W+k)*N+e], P at vp[(1*W+k)*N+e].
 //
 // One wavefront per lattice (the hardware dispatcher balances the variable-size lattices).
+//   1. wave-uniform part (scalar unit): plane words, offset, hit masks, counts.
+//   2. bit-parallel construction of the lattice's perspective bitstream in LDS (PStream, lattice.hpp):
+//      the rotated planes by __ballot, a table of row-rolled planes (one lane per entry), then one
+//      lane per hit: two masked column rolls and five-to-nine ds_or_b32.  No lookup table, no
+//      global vector load anywhere in this kernel (vector loads share the in-order vmcnt with the
+//      stores that follow; the per-lattice inputs arrive through scalar loads).
+//   3. expansion: a lane's 16-byte store needs VEC consecutive stream bits, and since one wave
+//      instruction advances the stream by 64*VEC bits (a multiple of 32) the lane's bit phase is
+//      loop-invariant: one ds_read2_b32, one 64-bit shift, the bit->element expansion, one
+//      global_store_dwordx4 per KiB written.
 // Ownership rule for the output: the stack is cut into 128-byte lines of the address space and a
 // line is written -- whole -- by the wave of the lattice that contains the line's FIRST element.
 // Two waves (usually on different XCDs, whose L2s are not coherent) therefore never write parts
 // of one line; measured +6.5 % over byte-exact segment ownership (tools/membench3.hip).
-//   * lines entirely inside the lattice's segment: the fast loop, one 16-byte store per lane,
-//     1 KiB = 8 whole lines per wave instruction, (perspective, cell) carried incrementally;
+//   * lines entirely inside the lattice's segment: the fast loop;
 //   * the last owned line, when the segment ends inside it: lanes 0..31 store one dword each; its
 //     trailing elements belong to the following lattice(s) and are resolved from their bit-planes.
 // The leading elements of a segment that sit in a line begun by an earlier lattice are written by
 // that lattice's wave, by the same rule.
-// Everything one wavefront does for one lattice of the stack (see the ownership rule above).
-// lut / hw / cw: the workgroup's LUT and this wave's LDS tables; all 64 lanes call it with the same e.
 template <int D, typename OutT>
 __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restrict__ vp, int64_t N,
                                               const int64_t* __restrict__ offsets, OutT* __restrict__ out,
-                                              int32_t* __restrict__ pos, int64_t capacity, const uint8_t* __restrict__ lut,
-                                              uint16_t* __restrict__ hw, uint8_t* __restrict__ cw, int* __restrict__ err,
-                                              int lane) {
+                                              int32_t* __restrict__ pos, int64_t capacity, PerspLds<D>& t,
+                                              int* __restrict__ err, int lane) {
     using L = Lat<D>;
+    using S = PStream<D>;
     using Enc = OutEnc<OutT>;
     constexpr int DD = L::DD, NQ = L::NQ, W = L::W;
     constexpr int VEC = 16 / (int)sizeof(OutT);              // elements per 16-byte lane store
@@ -692,14 +734,55 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     if (n == 0) return;
     const int64_t off = offsets[e];
     if (off + n > capacity) { if (lane == 0) atomicOr(err, ERR_CAPACITY); return; }
+
+    // ---- tables: rotated planes (ballot), row-rolled planes, column masks, hit list; zeroed stream
+    typename L::B rv, rp;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const int o = 64 * k + lane;
+        const bool in = o < DD;
+        const int oc = in ? o : 0;
+        rv.w[k] = __ballot(in && v.get(S::rot_src_v(oc)));
+        rp.w[k] = __ballot(in && p.get(S::rot_src_p(oc)));
+    }
+    if (lane < 4 * D) {
+        const int sel = lane / D, k = lane - sel * D;
+        typename L::B src;
+#pragma unroll
+        for (int w = 0; w < W; ++w) src.w[w] = sel == 0 ? v.w[w] : (sel == 1 ? p.w[w] : (sel == 2 ? rv.w[w] : rp.w[w]));
+        const typename L::B r = (src.shl(k * D) | src.shr(DD - k * D)) & L::full();      // roll_rows, branch-free (k = 0: shr(DD) = 0)
+#pragma unroll
+        for (int w = 0; w < W; ++w) t.rr[sel][k][w] = r.w[w];
+    }
+    if (lane < D) {
+        const typename L::B m = L::lowcols(lane);
+#pragma unroll
+        for (int w = 0; w < W; ++w) t.low[lane][w] = m.w[w];
+    }
     for (int c = lane; c < NQ; c += 64) {
         const int l = c >= DD, bit = c - l * DD;
-        cw[c] = (uint8_t)(l ? p.get(bit) : v.get(bit));
-        const int is_hit = l ? e1.get(bit) : e0.get(bit);
-        if (is_hit) hw[l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint16_t)(c * NQ);
+        if (l ? e1.get(bit) : e0.get(bit)) t.hits[l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint8_t)c;
+    }
+    {
+        const int nd4 = ((n * NQ + 31) / 32 + 2 + 3) / 4;     // <= BITS_DW / 4
+        uint4* b4 = reinterpret_cast<uint4*>(t.bits);
+        for (int i = lane; i < nd4; i += 64) b4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     wave_lds_sync();
 
+    // ---- one lane per hit: its perspective as two bit-planes, OR-ed into the stream
+    for (int k = lane; k < n; k += 64) {
+        const int h = t.hits[k];
+        const int layer = h >= DD, rem = h - layer * DD, i = rem / D, j = rem - i * D;
+        int rs, cs;
+        S::hit_shifts(layer, i, j, rs, cs);
+        typename L::B a, c, low;
+#pragma unroll
+        for (int w = 0; w < W; ++w) { a.w[w] = t.rr[2 * layer][rs][w]; c.w[w] = t.rr[2 * layer + 1][rs][w]; low.w[w] = t.low[cs][w]; }
+        const typename L::B ov = S::roll_cols_masked(a, cs, low), op = S::roll_cols_masked(c, cs, low);
+        S::emit(k, ov, op, [&](int idx, uint32_t val) { atomicOr(&t.bits[idx], val); });
+    }
+    wave_lds_sync();
 
     // positions (P,3) i32: (layer,row,col) of each hit.  Same ownership rule on its own 128-byte
     // lines (32 dwords): whole lines inside the lattice's [plo, phi) by 16-byte stores here, the
@@ -719,7 +802,7 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + j, hidx = k / 3;
-                o[j] = pos_value(hw[hidx] / NQ, k - 3 * hidx);
+                o[j] = pos_value(t.hits[hidx], k - 3 * hidx);
             }
             pseg[g] = make_int4(o[0], o[1], o[2], o[3]);
         }
@@ -732,47 +815,20 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
 
     // ---- whole lines inside the segment: [A, F)
     if (F > A) {
-        // Lane `lane` writes 16-byte groups lane, lane+64, ... of [A, F); its first element sits
-        // `rel` elements into the segment = perspective `pidx`, cell `cell`.  One iteration advances
-        // by 64*VEC elements = DP perspectives + DC cells: no division in the loop, 32-bit offsets
-        // from a wave-uniform base.
-        constexpr int STEP = 64 * VEC, DP = STEP / NQ, DC = STEP % NQ;
+        // Lane `lane` writes 16-byte groups lane, lane+64, ... of [A, F); group g holds the stream bits
+        // rel0 + g*VEC ... : the dword index advances by 2*VEC per iteration, the bit phase never changes.
         const int n_groups = (int)((F - A) / VEC);
         char* __restrict__ seg = reinterpret_cast<char*>(out + A);            // wave-uniform, 128-byte aligned
-        int pidx, cell;
-        {
-            const int rel = (int)(A - lo) + lane * VEC;
-            pidx = rel / NQ;
-            cell = rel - pidx * NQ;
-        }
+        const uint32_t rel0 = (uint32_t)(A - lo) + (uint32_t)lane * VEC;
+        const uint32_t ph = rel0 & 31u;
+        const uint32_t* __restrict__ bp = t.bits + (rel0 >> 5);
+        uint32_t w0 = 0, w1 = 0;
+        if (lane < n_groups) { w0 = bp[0]; w1 = bp[1]; }
         for (int gi = lane; gi < n_groups; gi += 64) {
-            uint32_t wd[4] = {0u, 0u, 0u, 0u};
-            int pp = pidx, cc = cell;
-#pragma unroll
-            for (int k = 0; k < VEC; k += 2) {              // NQ and cell are even: a pair never straddles two perspectives
-                const unsigned src2 = *reinterpret_cast<const unsigned short*>(&lut[hw[pp] + cc]);
-                const uint32_t b0 = cw[src2 & 255], b1 = cw[src2 >> 8];
-                if (Enc::BITS == 32) {
-                    wd[k] = __float_as_uint((float)b0);      // v_cvt_f32_ubyte0
-                    wd[k + 1] = __float_as_uint((float)b1);
-                } else {
-                    wd[k / EPW] |= ((0u - b0) & Enc::ONE) << ((k % EPW) * Enc::BITS);
-                    wd[(k + 1) / EPW] |= ((0u - b1) & Enc::ONE) << (((k + 1) % EPW) * Enc::BITS);
-                }
-                if (k + 2 < VEC) {
-                    cc += 2;
-                    const bool wrap = cc >= NQ;
-                    cc = wrap ? cc - NQ : cc;
-                    pp = wrap ? pp + 1 : pp;
-                }
-            }
-            const u32x4 v4 = {wd[0], wd[1], wd[2], wd[3]};
-            *reinterpret_cast<u32x4*>(seg + (uint32_t)gi * 16u) = v4;
-            cell += DC;
-            pidx += DP;
-            const bool wrap = cell >= NQ;
-            cell = wrap ? cell - NQ : cell;
-            pidx = wrap ? pidx + 1 : pidx;
+            const uint32_t wb = (uint32_t)(((((uint64_t)w1) << 32) | w0) >> ph);
+            bp += 2 * VEC;
+            if (gi + 64 < n_groups) { w0 = bp[0]; w1 = bp[1]; }              // next window is in flight while this one is stored
+            *reinterpret_cast<u32x4*>(seg + (uint32_t)gi * 16u) = expand_bits<OutT>(wb);
         }
     }
 
@@ -797,16 +853,14 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
         for (int j = 0; j < EPW; ++j) {                      // own elements
             const int64_t x = x0 + j;
             if (x < hi) {
-                const int rel = (int)(x - lo);
-                const int pidx = rel / NQ, cell = rel - pidx * NQ;
-                const uint32_t b = cw[lut[hw[pidx] + cell]];
+                const uint32_t b = S::window(t.bits, (uint32_t)(x - lo)) & 1u;
                 word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
             }
         }
     }
     if (p_lane && y < phi) {
         const int k = (int)(y - plo), hidx = k / 3;
-        pval = pos_value(hw[hidx] / NQ, k - 3 * hidx);
+        pval = pos_value(t.hits[hidx], k - 3 * hidx);
     }
     int64_t e2 = e + 1, spos = hi, ppos = phi;
     while (e2 < N && ((s_mixed && spos < s_line_end && spos < s_limit) || (p_mixed && ppos < p_line_end && ppos < p_limit))) {
@@ -823,7 +877,10 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
                 if (x >= spos && x < send) {
                     const int rel = (int)(x - spos);         // < LE
                     const int pidx = rel / NQ, cell = rel - pidx * NQ;
-                    const int src = lut[kth_hit<D>(f0, f1, pidx) * NQ + cell];
+                    const int h = kth_hit<D>(f0, f1, pidx);
+                    const int hl = h >= DD, hrem = h - hl * DD, hi_ = hrem / D, hj = hrem - hi_ * D;
+                    const int cc = cell >= DD, crem = cell - cc * DD, cr = crem / D, cs_ = crem - cr * D;
+                    const int src = L::persp_src(hl, hi_, hj, cc, cr, cs_);
                     const uint32_t b = (uint32_t)(src >= DD ? p2.get(src - DD) : v2.get(src));
                     word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
                 }
@@ -855,23 +912,14 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
 template <int D, typename OutT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restrict__ vp, int64_t N,
                                                          const int64_t* __restrict__ offsets, OutT* __restrict__ out,
-                                                         int32_t* __restrict__ pos, int64_t capacity,
-                                                         const uint8_t* __restrict__ lut_g, int* __restrict__ err) {
-    constexpr int NQ = Lat<D>::NQ;
+                                                         int32_t* __restrict__ pos, int64_t capacity, int* __restrict__ err) {
     constexpr int WAVES = THREADS / 64;
-    constexpr int LUT_BYTES = (NQ * NQ + 15) & ~15;
-    constexpr int NQP = (NQ + 3) & ~3;
-    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
-    __shared__ uint8_t cellv[WAVES][NQP];                    // syndrome cells (0/1) of the wave's lattice
-    __shared__ uint16_t hits[WAVES][NQP];                    // k-th hit -> flat qubit index * NQ (its LUT row offset)
-    for (int t = threadIdx.x; t < LUT_BYTES / 16; t += THREADS)
-        reinterpret_cast<uint4*>(lut)[t] = reinterpret_cast<const uint4*>(lut_g)[t];
-    __syncthreads();
+    __shared__ PerspLds<D> tables[WAVES];
     // the wave index is made provably uniform so that the lattice id, its plane words and its
     // offset live in SGPRs (scalar loads) and the hit masks are computed on the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t e = (int64_t)blockIdx.x * WAVES + wave;
-    if (e < N) persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, lut, hits[wave], cellv[wave], err, lane);
+    if (e < N) persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, tables[wave], err, lane);
 }
 
 // generateTransitionParallel on explicit u8 grids: one thread per output byte, the (hit, cell)

@@ -82,6 +82,21 @@ struct Bits {
         }
         return r;
     }
+    // shifts by 0 <= s < 64 (no word moves)
+    TQ_HD Bits shl_small(int s) const {
+        Bits r;
+#pragma unroll
+        for (int k = 0; k < W; ++k) r.w[k] = (w[k] << s) | (k > 0 ? (w[k > 0 ? k - 1 : 0] >> 1) >> (63 - s) : 0ull);
+        return r;
+    }
+    TQ_HD Bits shr_small(int s) const {
+        Bits r;
+#pragma unroll
+        for (int k = 0; k < W; ++k) r.w[k] = (w[k] >> s) | (k < W - 1 ? (w[k < W - 1 ? k + 1 : k] << 1) << (63 - s) : 0ull);
+        return r;
+    }
+    // dword j of the bitset (j compile-time after unrolling); 0 beyond the last word
+    TQ_HD uint32_t dword(int j) const { return (j >= 0 && j < 2 * W) ? (uint32_t)(w[(j >= 0 && j < 2 * W) ? j / 2 : 0] >> (32 * (j & 1))) : 0u; }
     TQ_HD Bits shr(int s) const {
         Bits r;
         const int ws = s >> 6, bs = s & 63;
@@ -221,6 +236,71 @@ struct Lat {
             }
             ov.w[k] = av; op.w[k] = ap;
         }
+    }
+};
+
+// ------------------------------------------------------------------ perspective bitstream
+// The perspective stack of ONE lattice as a bit string: bit  pidx*NQ + cell  = element `cell` of
+// the lattice's pidx-th perspective (hits in the reference's argwhere order).  The stack-write
+// kernel builds this string in LDS with bit-parallel plane operations and then only expands bits
+// into elements; no (hit, cell) -> source table is needed:
+//   * layer-0 hit (i,j): np.roll of (V,P) by (gs-i, gs-j)                        (shift_state)
+//   * layer-1 hit (i,j): rotate_state(shift_state(.)) = np.roll of the ONCE-rotated planes
+//     (RV,RP) = rotate_state(V,P) by rows +(j-gs), cols +(gs-i):
+//       P1[c,r,s] = state[c,(s+i-gs)%d, rotcol(r)+j-gs] = R[c,(r-(j-gs))%d,(s+(i-gs))%d]
+//     so every hit costs two row-rolled planes (shared by all hits with the same row amount, kept
+//     in a small table) and two column rolls.
+template <int D>
+struct PStream {
+    using L = Lat<D>;
+    using B = typename L::B;
+    static constexpr int NQ = L::NQ, DD = L::DD, W = L::W;
+    static constexpr int ND = (NQ + 31) / 32;                    // dwords of one perspective's NQ-bit string
+    static constexpr int MAX_DW = (NQ * NQ + 31) / 32 + 2;       // all NQ perspectives; +2: the 64-bit window read stays inside
+
+    // rotate_state (util.py:87-94) on bit-planes: source bit of output bit o = (r,s)
+    TQ_HD static int rot_src_p(int o) { const int r = o / D, s = o - r * D; return s * D + (D - 1 - r); }      // rot_p[r,s] = p[s,d-1-r]
+    TQ_HD static int rot_src_v(int o) { const int r = o / D, s = o - r * D; return s * D + (r ? D - r : 0); }  // rot_v[r,s] = v[s,(d-r)%d]
+    TQ_HD static void rotate_planes(const B& v, const B& p, B& rv, B& rp) {
+        rv = B::zero(); rp = B::zero();
+        for (int o = 0; o < DD; ++o) { rv.flip(o, v.get(rot_src_v(o))); rp.flip(o, p.get(rot_src_p(o))); }
+    }
+    // np.roll(a, +k, axis=1) with the low-column mask lowcols(k) supplied (table lookup in the kernel)
+    TQ_HD static B roll_cols_masked(const B& a, int k, const B& low) {
+        const B hi = L::full() ^ low;
+        return (a.shl_small(k) & hi) | (a.shr_small(D - k) & low);
+    }
+    // np.roll amounts (rows, cols) that turn the planes -- (V,P) for layer 0, (RV,RP) for layer 1 --
+    // into the perspective of hit (layer,i,j)
+    TQ_HD static void hit_shifts(int layer, int i, int j, int& rs, int& cs) {
+        const int ci = (L::GS - i + D) % D;
+        rs = layer ? (j - L::GS + D) % D : ci;
+        cs = layer ? ci : (L::GS - j + D) % D;
+    }
+    // dword j of the NQ-bit string  ov | (op << DD)  of one perspective (bits of ov/op above DD are 0)
+    TQ_HD static uint32_t string_dword(const B& ov, const B& op, int j) {
+        constexpr int q = DD / 32, r = DD % 32;
+        uint32_t t = ov.dword(j) | (op.dword(j - q) << r);
+        if (r) t |= (op.dword(j - q - 1) >> 1) >> (31 - r);
+        return t;
+    }
+    // OR the string of perspective `pidx` into the lattice's bitstream: orfn(dword index, value)
+    template <class OrFn>
+    TQ_HD static void emit(int pidx, const B& ov, const B& op, OrFn&& orfn) {
+        const uint32_t pos = (uint32_t)pidx * NQ;
+        const int base = (int)(pos >> 5), sh = (int)(pos & 31);
+        uint32_t prev = 0;
+#pragma unroll
+        for (int j = 0; j <= ND; ++j) {
+            const uint32_t cur = j < ND ? string_dword(ov, op, j) : 0u;
+            orfn(base + j, (cur << sh) | ((prev >> 1) >> (31 - sh)));
+            prev = cur;
+        }
+    }
+    // the 32 stream bits starting at bit `rel`
+    TQ_HD static uint32_t window(const uint32_t* bits, uint32_t rel) {
+        const uint32_t idx = rel >> 5, ph = rel & 31;
+        return (uint32_t)(((((uint64_t)bits[idx + 1]) << 32) | bits[idx]) >> ph);
     }
 };
 

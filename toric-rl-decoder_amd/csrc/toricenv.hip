@@ -134,27 +134,27 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
 
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
-                         int64_t capacity, const uint8_t* lut, int* err, hipStream_t stream) {
-    constexpr int THREADS = D <= 7 ? 256 : (D == 9 ? 512 : 1024);
+                         int64_t capacity, int* err, hipStream_t stream) {
+    constexpr int THREADS = 256;                             // waves of a workgroup share nothing: no barrier, no common table
     constexpr int WAVES = THREADS / 64;
     // One lattice per wave; the hardware dispatcher balances the variable-size lattices.  Persistent
     // waves (static, or drawing tickets), fixed aligned windows and cooperative workgroups were all
     // built or prototyped and are slower or equal in the real kernel (git history).
     const int64_t blocks = (n + WAVES - 1) / WAVES;
     hipLaunchKernelGGL((tq::k_persp_write<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
-                       offsets, (OutT*)out, pos, capacity, lut, err);
+                       offsets, (OutT*)out, pos, capacity, err);
     KCHECK();
     return TQ_OK;
 }
 
 template <int D>
 int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
-                       int64_t capacity, int dtype, const uint8_t* lut, int* err, hipStream_t stream) {
+                       int64_t capacity, int dtype, int* err, hipStream_t stream) {
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, lut, err, stream);
-        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, lut, err, stream);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, lut, err, stream);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, lut, err, stream);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -434,7 +434,7 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
     REQUIRE_ALIGNED16(out, "out");
     REQUIRE_ALIGNED16(positions, "positions");
     const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->lut, h->err, stream)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream)) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;
@@ -521,7 +521,7 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, lut, err, stream)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, err, stream)) return rc
     DISPATCH_D(d, CALL)
 #undef CALL
     return TQ_OK;

@@ -40,6 +40,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes), before HIP initialises
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")             # NN_11 leg: no exhaustive solver search on a fresh box
 
 import numpy as np  # noqa: E402
 
@@ -50,6 +51,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
 EPISODE = 76                    # a lattice is auto-reset once its step counter exceeds 75 (Distributed_mp.py:44)
 ENVS_N1, ENVS_MULTI = 65536, 131072     # BASELINE configs[2] / configs[4] lattices per GPU
+NN_CHUNK = 16384                # perspectives per NN_11 forward call
 
 
 def parse(argv=None):
@@ -71,7 +73,7 @@ def parse(argv=None):
                          "N>1, north_star), hbm = ring in rank 0's HBM only")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
-    ap.add_argument("--nn-steps", type=int, default=2,
+    ap.add_argument("--nn-steps", type=int, default=1,
                     help="N=1: timed steps of the NN_11-in-the-loop leg (configs[2] as written); 0 = skip")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
     ap.add_argument("--graph", action="store_true",
@@ -81,9 +83,9 @@ def parse(argv=None):
                     help="explore: eps=1 selection in the fused kernel (default, the env path alone); "
                          "nn11: NN_11 forward on the stack + device eps-greedy selection in the main loop (NN-bound)")
     ap.add_argument("--eps", type=float, default=0.1, help="epsilon of the nn11 policy")
-    ap.add_argument("--nn-dtype", default="bf16", choices=["f32", "bf16"],
-                    help="dtype of the NN_11 forward: bf16 autocast (default; f32 upstream runs at ~18 TFLOP/s in stock "
-                         "MIOpen, 23 s per step at 65 536 lattices -- measured once, DESIGN.md section 7)")
+    ap.add_argument("--nn-dtype", default="f32", choices=["f32", "bf16"],
+                    help="dtype of the NN_11 forward: f32 as upstream (default; ~18 TFLOP/s in stock MIOpen = 23 s per "
+                         "step at 65 536 lattices) or bf16 autocast")
     return ap.parse_args(argv)
 
 
@@ -302,8 +304,10 @@ def main():
             act = None
             if model_ is not None:                                    # configs[2] as written: stack -> NN_11 -> selection
                 P = int(off[-1].item())
+                # fixed-shape chunks (one MIOpen problem per layer): the rows past P in the last chunk are
+                # stale stack rows whose Q-values are cut off again
                 with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.nn_dtype == "bf16"):
-                    q = torch.cat([model_(sh.stack[i:min(i + 32768, P)]) for i in range(0, P, 32768)]).float()
+                    q = torch.cat([model_(sh.stack[i:i + NN_CHUNK]) for i in range(0, P, NN_CHUNK)])[:P].float()
                 act, _ = envs.selectAction(q, sh.eps, positions=sh.positions, offsets=off)
             envs.actorStep(act, block=blk, slot=t % flush, want_actions=True)
             if blk is not None and (t + 1) % flush == 0:
@@ -414,8 +418,12 @@ def main():
         state["tg"], state["model"] = None, make_model()
         sh0 = shards[0]
         base = W + K
+        print("[bench] nn_in_loop leg: warm-up step (MIOpen picks its kernels) ...", file=sys.stderr, flush=True)
+        t0 = time.perf_counter()
         one_step(0, base)                                             # warm-up: MIOpen picks its kernels
         torch.cuda.synchronize(device)
+        print("[bench] nn_in_loop leg: warm-up took %.1f s; timing %d step(s) ..." % (time.perf_counter() - t0, args.nn_steps),
+              file=sys.stderr, flush=True)
         t0 = time.perf_counter()
         for i in range(args.nn_steps):
             one_step(0, base + 1 + i)

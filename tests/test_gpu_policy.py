@@ -404,3 +404,39 @@ def test_transition_gather_rccl_single_rank_with_host_drain(T):
         gpu.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_nn11_on_the_device_stack(T):
+    """BASELINE configs[2] as written, small: generatePerspective feeds NN_11 (the reference's
+    architecture, src/nn/torch/NN.py:10-45, random init) on the device; its forward must agree with
+    the same module on the CPU in fp32 (1e-4 absolute: Q-values of a random-init net are O(0.1)),
+    and the device selection on those Q-values must be the oracle's choice."""
+    d, n = 7, 256
+    env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+    gpu = T.EnvSet(env, n, seed=17, numpy_io=False)
+    ora = O.OracleEnvSet(d, n, 0.1, seed=17)
+    gpu.resetAll()
+    ora.resetAll()
+    torch.manual_seed(0)
+    model = T.NN_11(d, 3).eval()
+    model_gpu = T.NN_11(d, 3).eval()
+    model_gpu.load_state_dict(model.state_dict())
+    model_gpu.to(gpu.device)
+    per, pos, cnt = gpu.generatePerspective(dtype=torch.float32)
+    bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+    assert np.array_equal(per.cpu().numpy(), bp.astype(np.float32))
+    with torch.no_grad():
+        q_gpu = model_gpu(per).float()
+        q_cpu = model(torch.from_numpy(bp.astype(np.float32)))
+    assert q_gpu.shape == (bp.shape[0], 3)
+    assert float((q_gpu.cpu() - q_cpu).abs().max()) < 1e-4              # tolerance stated: fp32 conv, different summation order
+    eps = np.full(n, 0.25)
+    act, qv = gpu.selectAction(q_gpu, eps, positions=pos)
+    oact, oqv, _ = O.select_action_batch(q_gpu.cpu().numpy(), boff, bpos, eps, ora.seed, ora.env_ids, ora.episodes, ora.steps)
+    assert np.array_equal(act.cpu().numpy(), oact) and np.array_equal(qv.cpu().numpy(), oqv)
+    # and through the reference-signature entry point (numpy in / numpy out)
+    T.seed_select(5)
+    a2, q2 = T.selectActionBatch(3, 0.0, d // 2, d, ora.states.astype(np.int64), model_gpu, "cuda")
+    o2, oq2, _ = O.select_action_batch(q_gpu.cpu().numpy(), boff, bpos, 0.0, 5, np.arange(n), 0, 0, domain=O.DOMAIN_SEL_CALL)
+    assert np.array_equal(a2, o2) and np.array_equal(q2, oq2.astype(np.float64))
+    gpu.close()

@@ -79,6 +79,11 @@ int tq_destroy(tq_env* h);
  * evaluation.py:175), max_actions_per_episode (default 75, Distributed_mp.py:44; used only by
  * tq_actor_step's auto-reset). */
 int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int max_steps_per_episode);
+/* gym config "min_qubit_errors": 0 (default, every config of the reference tree) = depolarizing
+ * sampler at p_error; n > 0 = every reset places exactly n errors on uniformly chosen distinct
+ * qubits with uniform Paulis (the fixed-n sampler, results/small_p_error_test.py:34-40; p_error
+ * is then unused), still redrawn until the syndrome is non-empty. */
+int tq_set_min_qubit_errors(tq_env* h, int n_errors);
 /* p_error schedule of the actor's reset policy (Actor_mp.py:41-46,176-180) for tq_actor_step. */
 int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_final, double p_delta);
 

@@ -57,6 +57,7 @@ DOMAIN_ERR = 0
 DOMAIN_SEL = 1
 DOMAIN_PERR = 2
 DOMAIN_SEL_CALL = 3
+DOMAIN_NERR = 4
 MAX_RESET_ROUNDS = 4096
 TERMINAL_REWARD = 100.0  # evaluation.py:175, Learner_mp.py:151 (clamp +-100)
 
@@ -165,7 +166,30 @@ def sample_errors(seed, env_ids, episodes, rounds, p_errors, d):
     return np.where(err, pauli, 0).astype(np.uint8).reshape(-1, 2, d, d)
 
 
-def reset_lattices(seed, env_ids, episodes, p_errors, d):
+def sample_n_errors(seed, env_ids, episodes, rounds, n_err, d):
+    """One draw round of the fixed-n sampler (config "min_qubit_errors" = n > 0): exactly n errors on
+    uniformly chosen distinct qubits, Pauli uniform -- generateNRandomErrors,
+    results/small_p_error_test.py:34-40 (there: n Paulis shuffled over the 2*d*d positions).
+    Selection sampling in qubit index order with one Philox draw per qubit (DOMAIN_NERR): qubit c
+    is taken iff (w0 * (NQ - c)) >> 32 < n - taken.  PARITY UNPINNED like the rest of the env half."""
+    env_ids = np.asarray(env_ids, dtype=np.uint64).reshape(-1, 1)
+    episodes = np.asarray(episodes, dtype=np.uint64).reshape(-1, 1)
+    rounds = np.asarray(rounds, dtype=np.uint64).reshape(-1, 1)
+    nq = 2 * d * d
+    q = np.arange(nq, dtype=np.uint64).reshape(1, -1) | np.uint64(DOMAIN_NERR << 24)
+    k0, k1 = _key(seed)
+    w0, w1, _, _ = philox4x32(env_ids, episodes, rounds, q, k0, k1)
+    pauli = 1 + _mulhi(w1, 3)
+    out = np.zeros(w0.shape, np.uint8)
+    taken = np.zeros(w0.shape[0], np.int64)
+    for c in range(nq):
+        err = _mulhi(w0[:, c], nq - c) < (int(n_err) - taken)
+        taken += err
+        out[:, c] = np.where(err, pauli[:, c], 0)
+    return out.reshape(-1, 2, d, d)
+
+
+def reset_lattices(seed, env_ids, episodes, p_errors, d, min_errors=0):
     """env.reset(p_error) for a batch: redraw until >= 1 defect.
 
     Evidence for reset-until-non-terminal: small_p_error_test.py:109-120 and
@@ -182,7 +206,10 @@ def reset_lattices(seed, env_ids, episodes, p_errors, d):
     for r in range(MAX_RESET_ROUNDS):
         if todo.size == 0:
             break
-        qb = sample_errors(seed, env_ids[todo], episodes[todo], r, p[todo], d)
+        if min_errors > 0:
+            qb = sample_n_errors(seed, env_ids[todo], episodes[todo], r, min_errors, d)
+        else:
+            qb = sample_errors(seed, env_ids[todo], episodes[todo], r, p[todo], d)
         st = syndrome(qb)
         qubits[todo] = qb
         state[todo] = st
@@ -465,7 +492,8 @@ class OracleEnvSet:
     """
 
     def __init__(self, size, no_envs, p_error=0.1, seed=0, first_env_id=0,
-                 terminal_reward=TERMINAL_REWARD):
+                 terminal_reward=TERMINAL_REWARD, min_qubit_errors=0):
+        self.min_qubit_errors = int(min_qubit_errors)
         self.size = int(size)
         self.no_envs = int(no_envs)
         self.p_error = float(p_error)
@@ -484,7 +512,7 @@ class OracleEnvSet:
             p = np.full(idx.shape[0], self.p_error)
         else:
             p = np.asarray(p_errors, np.float64).reshape(-1)
-        q, s = reset_lattices(self.seed, self.env_ids[idx], self.episodes[idx], p, self.size)
+        q, s = reset_lattices(self.seed, self.env_ids[idx], self.episodes[idx], p, self.size, self.min_qubit_errors)
         self.qubits[idx] = q
         self.states[idx] = s
         self.episodes[idx] += 1

@@ -94,6 +94,17 @@ static void t_reset(int n, uint64_t seed, int64_t first_env, const uint32_t* epi
     }
 }
 template <int D>
+static void t_reset_n(int n, uint64_t seed, int64_t first_env, const uint32_t* episodes, int n_err,
+                      uint8_t* q, uint8_t* st) {
+    using L = Lat<D>;
+    for (int e = 0; e < n; ++e) {
+        typename L::State s;
+        reset_lattice_n<D>(s, seed, (uint32_t)(first_env + e), episodes[e], n_err);
+        unpack_qubits<D>(s, q + (size_t)e * L::NQ);
+        unpack_state<D>(s.v, s.p, st + (size_t)e * L::NQ);
+    }
+}
+template <int D>
 static void t_step(int n, uint8_t* q, const int32_t* act, uint8_t* st, int32_t* ground) {
     using L = Lat<D>;
     for (int e = 0; e < n; ++e) {
@@ -187,6 +198,12 @@ int shim_perspective(int d, int n, const uint8_t* st, const int32_t* act, uint8_
 int shim_reset(int d, int n, uint64_t seed, int64_t first_env, const uint32_t* episodes, const double* p,
                uint8_t* q, uint8_t* st, int32_t* rounds) {
 #define C_(D) t_reset<D>(n, seed, first_env, episodes, p, q, st, rounds)
+    DISPATCH(d, C_)
+#undef C_
+}
+int shim_reset_n(int d, int n, uint64_t seed, int64_t first_env, const uint32_t* episodes, int n_err, uint8_t* q,
+                 uint8_t* st) {
+#define C_(D) t_reset_n<D>(n, seed, first_env, episodes, n_err, q, st)
     DISPATCH(d, C_)
 #undef C_
 }

@@ -625,3 +625,37 @@ def test_generate_perspective_of_explicit_states(T):
     assert per.dtype == np.float32 and np.array_equal(per, bp.astype(np.float32))
     assert np.array_equal(pos, bpos) and np.array_equal(cnt, bcnt)
     gpu.close()
+
+
+@pytest.mark.parametrize("d,n_err", [(3, 1), (5, 3), (7, 4), (9, 162)])
+def test_min_qubit_errors_sampler(T, d, n_err):
+    """gym config "min_qubit_errors" = n > 0: every reset (resetAll, indexed, and the auto-reset fused
+    into the actor step) places exactly n errors; bit-exact against the oracle's fixed-n sampler."""
+    n = 700
+    env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": n_err, "p_error": 0.1})
+    gpu = T.EnvSet(env, n, seed=9, first_env_id=3, numpy_io=False, max_steps_per_episode=4)
+    ora = O.OracleEnvSet(d, n, 0.1, seed=9, first_env_id=3, min_qubit_errors=n_err)
+    gpu.resetAll()
+    ora.resetAll()
+    q = gpu.getQubits().cpu().numpy()
+    assert np.array_equal(q, ora.qubits) and ((q != 0).reshape(n, -1).sum(1) == n_err).all()
+    idx = np.arange(5, n, 9)
+    gpu.resetTerminalEnvs(torch.as_tensor(idx, dtype=torch.int32, device=gpu.device))
+    ora.resetTerminalEnvs(idx)
+    assert np.array_equal(gpu.getQubits().cpu().numpy(), ora.qubits)
+    for t in range(12):                                       # fused steps: lattices time out after 4 steps and are re-drawn
+        bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+        oact, _, _ = O.select_action_batch(np.zeros((bp.shape[0], 3), np.float32), boff, bpos, 1.0, ora.seed,
+                                           ora.env_ids, ora.episodes, ora.steps)
+        gpu.perspectiveCounts()
+        act, rew, term = gpu.actorStep(None)
+        _, orew, oterm, _ = ora.step(oact)
+        assert np.array_equal(act.cpu().numpy(), oact) and np.array_equal(term.cpu().numpy().astype(bool), oterm)
+        ridx = np.nonzero(oterm | (ora.steps > 4))[0]
+        if ridx.size:
+            ora.resetTerminalEnvs(ridx)
+        assert np.array_equal(gpu.getQubits().cpu().numpy(), ora.qubits)
+        assert np.array_equal(gpu.getStates().cpu().numpy(), ora.states)
+    assert ora.episodes.max() >= 3
+    gpu.check()
+    gpu.close()

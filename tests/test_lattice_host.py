@@ -96,6 +96,25 @@ def test_reset_matches_oracle(shim, d):
     assert rounds.min() >= 1 and (d > 3 or rounds.max() > 1)
 
 
+@pytest.mark.parametrize("d", SIZES)
+def test_fixed_n_sampler_matches_oracle(shim, d):
+    """config "min_qubit_errors" = n: exactly n errors per reset, uniform over positions and Paulis."""
+    rng = np.random.default_rng(300 + d)
+    n = 400
+    ep = rng.integers(0, 5, n).astype(np.uint32)
+    for n_err in (1, d // 2 + 1, 2 * d * d):
+        q, st = np.zeros((n, 2, d, d), np.uint8), np.zeros((n, 2, d, d), np.uint8)
+        shim.shim_reset_n(d, n, C.c_uint64(7), C.c_int64(11), P(ep), n_err, P(q), P(st))
+        oq, os_ = O.reset_lattices(7, np.arange(11, 11 + n), ep, 0.1, d, min_errors=n_err)
+        assert np.array_equal(q, oq) and np.array_equal(st, os_)
+        assert ((q != 0).reshape(n, -1).sum(1) == n_err).all() and st.reshape(n, -1).any(1).all()
+    # uniformity over positions (one error, many lattices): every qubit is hit about equally often
+    big = 20000
+    q1, _ = O.reset_lattices(1, np.arange(big), 0, 0.1, d, min_errors=1)
+    hits = (q1 != 0).reshape(big, -1).sum(0)
+    assert hits.sum() == big and hits.min() > 0.6 * big / (2 * d * d)
+
+
 def test_philox_header(shim):
     out = np.zeros(4, np.uint32)
     shim.shim_philox(P(np.array([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], np.uint32)),

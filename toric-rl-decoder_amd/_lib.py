@@ -23,6 +23,7 @@ SYMBOLS = [
     ("tq_create", _i, [C.POINTER(_vp), _i, _i, _i, _u64, _i64]),
     ("tq_destroy", _i, [_vp]),
     ("tq_set_params", _i, [_vp, _d, _d, _i]),
+    ("tq_set_min_qubit_errors", _i, [_vp, _i]),
     ("tq_set_perror_schedule", _i, [_vp, _i, _d, _d, _d]),
     ("tq_num_envs", _i, [_vp]),
     ("tq_size", _i, [_vp]),

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_reset(uint64_t* __restrict__ planes, ui
                                                const double* __restrict__ p_err, double p_default,
                                                uint64_t seed, int64_t first_env, int64_t N,
                                                int64_t* __restrict__ part256, uint32_t* __restrict__ mark,
-                                               uint32_t epoch, int* __restrict__ err) {
+                                               uint32_t epoch, int min_err, int* __restrict__ err) {
     using L = Lat<D>;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t m = idx ? n_idx : N;
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void k_reset(uint64_t* __restrict__ planes, ui
     if (e >= 0 && e < N) {
         typename L::State s;
         const uint32_t ep = episodes[e];
-        reset_lattice<D>(s, seed, (uint32_t)(first_env + e), ep, p_err ? p_err[t] : p_default);
+        if (min_err > 0) reset_lattice_n<D>(s, seed, (uint32_t)(first_env + e), ep, min_err);   // config "min_qubit_errors"
+        else reset_lattice<D>(s, seed, (uint32_t)(first_env + e), ep, p_err ? p_err[t] : p_default);
         if (!(s.v.any() || s.p.any())) atomicOr(err, ERR_RESET_ROUNDS);
         store_state<D>(planes, N, e, s);
         episodes[e] = ep + 1;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
                                                     int32_t* __restrict__ actions_out, float* __restrict__ rewards,
                                                     uint8_t* __restrict__ terminals, BlockView blk, int has_block,
                                                     int64_t slot_base, PerrSchedule sched, float terminal_reward,
-                                                    int max_steps, uint64_t seed, int64_t first_env, int64_t N,
+                                                    int max_steps, int min_err, uint64_t seed, int64_t first_env, int64_t N,
                                                     int* __restrict__ err, int64_t* __restrict__ part256) {
     using L = Lat<D>;
     // every lane stays alive to the end (the reset below is wave-cooperative); lanes past N work on a
@@ -376,8 +377,12 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
         const int src = (int)__ffsll((long long)pending) - 1;
         pending &= pending - 1;
         typename L::State fresh;
-        reset_lattice_wave<D>(fresh, seed, (uint32_t)__shfl((int)env, src, 64), (uint32_t)__shfl((int)ep, src, 64),
-                              __shfl(p, src, 64), lane);
+        if (min_err > 0) {                                   // fixed-n sampler: sequential by nature, done by the lane itself
+            if (lane == src) reset_lattice_n<D>(fresh, seed, env, ep, min_err);
+        } else {
+            reset_lattice_wave<D>(fresh, seed, (uint32_t)__shfl((int)env, src, 64), (uint32_t)__shfl((int)ep, src, 64),
+                                  __shfl(p, src, 64), lane);
+        }
         if (lane == src) {
             if (!(fresh.v.any() || fresh.p.any())) atomicOr(err, ERR_RESET_ROUNDS);
             s = fresh; ep += 1; st = 0;

@@ -321,7 +321,7 @@ TQ_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     return U4{c0, c1, c2, c3};
 }
 
-enum : uint32_t { DOMAIN_ERR = 0, DOMAIN_SEL = 1, DOMAIN_PERR = 2, DOMAIN_SEL_CALL = 3 };
+enum : uint32_t { DOMAIN_ERR = 0, DOMAIN_SEL = 1, DOMAIN_PERR = 2, DOMAIN_SEL_CALL = 3, DOMAIN_NERR = 4 };
 constexpr int MAX_RESET_ROUNDS = 4096;
 
 TQ_HD U4 draw(uint64_t seed, uint32_t env, uint32_t episode, uint32_t round, uint32_t domain, uint32_t index) {
@@ -347,6 +347,43 @@ TQ_HD int reset_lattice(typename Lat<D>::State& s, uint64_t seed, uint32_t env, 
                     const U4 w = draw(seed, env, episode, (uint32_t)r, DOMAIN_ERR,
                                       (uint32_t)(l * L::DD + 64 * k + bit));
                     const int err = u01(w.x) < p;
+                    const uint32_t pauli = 1 + mulhi32(w.y, 3);
+                    ax |= (uint64_t)(err & ((pauli == 1) | (pauli == 2))) << bit;
+                    az |= (uint64_t)(err & (int)(pauli >> 1)) << bit;
+                }
+                x.w[k] = ax; z.w[k] = az;
+            }
+            s.x[l] = x; s.z[l] = z;
+        }
+        L::syndrome(s);
+        if (s.v.any() || s.p.any()) return r + 1;
+    }
+    return r;
+}
+
+// env.reset with config "min_qubit_errors" = n > 0: exactly n errors on uniformly chosen distinct
+// qubits, Pauli uniform (the fixed-n sampler, results/small_p_error_test.py:34-40; p_error is not
+// used), redrawn until the syndrome is non-empty.  Selection sampling (Knuth's algorithm S) over the
+// qubits in index order: qubit c is taken iff floor(w0 * (NQ - c) / 2^32) < n - taken -- one Philox
+// draw per qubit, no permutation array.
+template <int D>
+TQ_HD int reset_lattice_n(typename Lat<D>::State& s, uint64_t seed, uint32_t env, uint32_t episode, int n_err) {
+    using L = Lat<D>;
+    int r = 0;
+    for (; r < MAX_RESET_ROUNDS; ++r) {
+        int taken = 0;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            typename L::B x, z;
+#pragma unroll
+            for (int k = 0; k < L::W; ++k) {
+                uint64_t ax = 0, az = 0;
+                const int nb = (L::DD - 64 * k) < 64 ? (L::DD - 64 * k) : 64;
+                for (int bit = 0; bit < nb; ++bit) {
+                    const int c = l * L::DD + 64 * k + bit;
+                    const U4 w = draw(seed, env, episode, (uint32_t)r, DOMAIN_NERR, (uint32_t)c);
+                    const int err = (int)mulhi32(w.x, (uint32_t)(L::NQ - c)) < n_err - taken;
+                    taken += err;
                     const uint32_t pauli = 1 + mulhi32(w.y, 3);
                     ax |= (uint64_t)(err & ((pauli == 1) | (pauli == 2))) << bit;
                     az |= (uint64_t)(err & (int)(pauli >> 1)) << bit;

@@ -167,6 +167,7 @@ struct tq_env {
     int64_t first_env;
     double terminal_reward;
     int max_steps;
+    int min_err;           // config "min_qubit_errors": 0 = depolarizing sampler, n > 0 = exactly n errors per reset
     tq::PerrSchedule sched;
     uint64_t* planes;      // [6][W][N]
     uint64_t* prev;        // [2][W][N]
@@ -279,6 +280,13 @@ int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int
     return TQ_OK;
 }
 
+int tq_set_min_qubit_errors(tq_env* h, int n_errors) {
+    if (!h) return fail(TQ_E_INVALID, "NULL handle");
+    if (n_errors < 0 || n_errors > 2 * h->d * h->d) return fail(TQ_E_INVALID, "min_qubit_errors must be in [0, 2*d*d]");
+    h->min_err = n_errors;
+    return TQ_OK;
+}
+
 int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_final, double p_delta) {
     DeviceGuard guard;
     if (int rc = guard.enter(h)) return rc;
@@ -303,7 +311,7 @@ int tq_reset_all(tq_env* h, const double* p_err, void* stream_) {
     HANDLE(h);
 #define CALL(D) hipLaunchKernelGGL(tq::k_reset<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->episodes, \
         h->steps, h->counts, (const int32_t*)nullptr, 0, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n, \
-        h->partial, h->mark, 0u, h->err)
+        h->partial, h->mark, 0u, h->min_err, h->err)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
@@ -321,7 +329,7 @@ int tq_reset_idx(tq_env* h, const int32_t* idx, int n_idx, const double* p_err, 
     }
 #define CALL(D) hipLaunchKernelGGL(tq::k_reset<D>, grid1(n_idx, 256), dim3(256), 0, stream, h->planes, h->episodes, \
         h->steps, h->counts, idx, n_idx, p_err, h->sched.p_default, h->seed, h->first_env, (int64_t)h->n, (int64_t*)nullptr, \
-        h->mark, h->reset_epoch, h->err)
+        h->mark, h->reset_epoch, h->min_err, h->err)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
@@ -668,7 +676,7 @@ int tq_actor_step(tq_env* h, const int32_t* actions, int32_t* actions_out, float
     }
 #define CALL(D) hipLaunchKernelGGL(tq::k_actor_step<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->episodes, \
         h->steps, h->counts, h->p_roof, actions, actions_out, rewards, terminals, b, block ? 1 : 0, slot_base, h->sched, \
-        (float)h->terminal_reward, h->max_steps, h->seed, h->first_env, (int64_t)h->n, h->err, h->partial)
+        (float)h->terminal_reward, h->max_steps, h->min_err, h->seed, h->first_env, (int64_t)h->n, h->err, h->partial)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();

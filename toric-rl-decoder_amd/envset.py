@@ -65,8 +65,9 @@ class ToricEnv:
         self.system_size = int(config.get("size", 3))
         if self.system_size not in SUPPORTED_SIZES:
             raise ValueError(f"size must be odd in {SUPPORTED_SIZES}, got {self.system_size}")
-        if int(config.get("min_qubit_errors", 0)) != 0:
-            raise ValueError("min_qubit_errors != 0 is not supported (always 0 upstream: Distributed_mp.py:74)")
+        self.min_qubit_errors = int(config.get("min_qubit_errors", 0))
+        if not 0 <= self.min_qubit_errors <= 2 * self.system_size ** 2:
+            raise ValueError("min_qubit_errors must be in [0, 2*size*size]")
         self.p_error = float(config.get("p_error", 0.1))
         self.terminal_reward = float(config.get("terminal_reward", 100.0))
         self.action_space = _ActionSpace(self.system_size)
@@ -216,6 +217,9 @@ class EnvSet:
             check(self._L.tq_create(C.byref(self._h), self.no_envs, self.size, self.device.index,
                                     C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), self.first_env_id))
         check(self._L.tq_set_params(self._h, self.p_error, self.terminal_reward, self.max_steps_per_episode))
+        # gym config "min_qubit_errors" (always 0 in the reference's own configs): n > 0 = fixed-n sampler
+        self.min_qubit_errors = int(getattr(env, "min_qubit_errors", 0))
+        check(self._L.tq_set_min_qubit_errors(self._h, self.min_qubit_errors))
         n, d, dev = self.no_envs, self.size, self.device
         self._state_u8 = torch.zeros((n, 2, d, d), dtype=torch.uint8, device=dev)
         self._rewards = torch.zeros(n, dtype=torch.float32, device=dev)

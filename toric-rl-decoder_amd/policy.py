@@ -141,8 +141,8 @@ def evaluate(model, env, env_config, grid_shift, device, prediction_list_p_error
              seed=0, chunk=1 << 16):
     """evaluation.py:10-124 with the episodes of one p_error run side by side as one EnvSet.
     -> (error_corrected_list, ground_state_list, average_number_of_steps_list, mean_q_list, failed_syndroms)."""
-    if minimum_nbr_of_qubit_errors:
-        raise ValueError("minimum_nbr_of_qubit_errors != 0 is not supported")
+    # like upstream, `minimum_nbr_of_qubit_errors` is accepted and unused: the sampler is chosen by
+    # env_config["min_qubit_errors"] (evaluation.py:51)
     model.to(device)
     model.eval()
     size = int(env_config["size"])
@@ -152,7 +152,7 @@ def evaluate(model, env, env_config, grid_shift, device, prediction_list_p_error
     corrected, ground, steps_avg, mean_q = np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
     failed = []
     for i, p in enumerate(prediction_list_p_error):
-        cfg = {"size": size, "min_qubit_errors": 0, "p_error": float(p)}
+        cfg = {"size": size, "min_qubit_errors": int(env_config.get("min_qubit_errors", 0)), "p_error": float(p)}
         envs = EnvSet(ToricEnv(cfg, device=device, seed=seed + i), num_of_episodes, device=device, numpy_io=False)
         envs.resetAll()
         init_q = envs.getQubits().clone()

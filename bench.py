@@ -171,7 +171,48 @@ class Shard:
     """One sub-shard of this GPU's lattices with its stream and its caller-owned output buffers."""
 
 
-def dry_run(args, world, rank):
+def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm):
+    """The same pass over a batch of `n` lattices on the current stream, no events, no collective:
+    burn-in, `warm` untimed and `steps` timed steps.  -> (seconds, perspectives in the timed steps).
+    Used at N=1 to time one GPU on the per-GPU shape of the N>1 runs (configs[4]: 131 072 lattices), so
+    the scaling curve can be read like for like."""
+    nq = 2 * d * d
+    envs = T.EnvSet(env, n, device=device, seed=seed, first_env_id=first, numpy_io=False)
+    envs.resetAll()
+    stack = torch.empty((n * nq, 2, d, d), dtype=tdtype, device=device)
+    positions = torch.empty((n * nq, 3), dtype=torch.int32, device=device)
+    offs = torch.zeros((warm + steps, (n + 2) & ~1), dtype=torch.int64, device=device)
+    blocks = [envs.newTransitionBlock(steps=flush) for _ in range(2)]
+    for t in range(EPISODE):
+        idx = torch.arange(t, n, EPISODE, dtype=torch.int32, device=device)
+        if idx.numel():
+            envs.resetTerminalEnvs(idx)
+        envs.actorStep(None, want_actions=False)
+
+    def step(t):
+        off = offs[t][:n + 1]
+        envs.perspectiveCounts(off)
+        envs.writePerspectives(stack, positions, off)
+        blk = blocks[(t // flush) & 1]
+        envs.actorStep(None, block=blk, slot=t % flush, want_actions=True)
+        if (t + 1) % flush == 0:
+            blk.computePriorities(n, flush, None, 0.95)
+
+    for t in range(warm):
+        step(t)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for t in range(warm, warm + steps):
+        step(t)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    P = float(offs[warm:, n].sum().item())
+    envs.check()
+    envs.close()
+    return dt, P
+
+
+def dry_run(args, world, rank, result_out):
     """TORIC_BENCH_DRY_RUN=1: launcher / rendezvous check only (CPU test of the N>1 command form on a
     box without a GPU): init the process group, agree on the world size, print a line that says so.
     Nothing is measured and `value` is null."""
@@ -187,7 +228,8 @@ def dry_run(args, world, rank):
         print(json.dumps({"metric": "env steps/sec (batched) at d=%d p=%g" % (args.size, args.p_error), "value": None,
                           "unit": "env-steps/s", "n_gpus": dist.get_world_size(), "steps": args.steps,
                           "warmup": args.warmup, "dry_run": True, "ranks_seen": int(seen.item()),
-                          "config": {"workload": "launcher dry run: no GPU work", "collective": backend}}), flush=True)
+                          "config": {"workload": "launcher dry run: no GPU work", "collective": backend}}),
+              file=result_out, flush=True)
     dist.destroy_process_group()
 
 
@@ -195,12 +237,18 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args)
+    # ONE JSON line on stdout, nothing else: native libraries print there too (RCCL writes its version
+    # banner to stdout when the communicator comes up), so file descriptor 1 is pointed at stderr for
+    # the rest of the process and the result line goes through a private copy of the real stdout.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     if os.environ.get("TORIC_BENCH_DRY_RUN") == "1":
-        return dry_run(args, world, rank)
+        return dry_run(args, world, rank, result_out)
 
     import torch
     import torch.distributed as dist
@@ -412,6 +460,16 @@ def main():
         hbm_ring = {"value": total_steps / el2, "ms_per_step": 1e3 * el2 / K,
                     "note": "same run, transition ring left in rank 0's HBM (no D2H drain)"}
 
+    # ---- N=1 on the default shape: one GPU on the per-GPU shape of the N>1 runs (configs[4]), like for like
+    shard_leg = None
+    if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore":
+        k2, w2 = max(8, min(K, 40)), 8
+        dt2, P2 = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2)
+        shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
+                     "perspectives_per_sec": P2 / dt2,
+                     "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
+                             "no collective: the like-for-like base of the scaling curve"}
+
     # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured once at size
     nn_leg = None
     if world == 1 and args.nn_steps > 0 and args.policy == "explore" and graph is None and S == 1:
@@ -469,6 +527,8 @@ def main():
         }
         if hbm_ring is not None:
             res["hbm_ring"] = hbm_ring
+        if shard_leg is not None:
+            res["configs4_shard_on_one_gpu"] = shard_leg
         if use_events:
             p_mean = float(p_timed.mean().item())
             alg = p_mean * (nq * esize + 12) + ns * nq                 # P*(B_p+12) + N*2d^2, per launch
@@ -508,7 +568,7 @@ def main():
             res["nn_in_loop"] = nn_leg
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(d, args.p_error, args.seed, args.cpu_seconds)
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=result_out, flush=True)
     for sh in shards:
         sh.envs.close()
     if dist_on:

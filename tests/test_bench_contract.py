@@ -66,6 +66,24 @@ def test_bench_two_ranks_share_the_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_rccl_path_keeps_stdout_to_one_line():
+    """The collective path over RCCL (a world of one rank on this box, TORIC_FORCE_DIST=1) with delivery to
+    the pinned host ring: RCCL prints its version banner on stdout when the communicator comes up -- the
+    bench must still print exactly one line there -- and the line carries the HBM-ring rate beside it."""
+    env = dict(os.environ, TORIC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--envs", "8192",
+                        "--cpu-seconds", "0", "--nn-steps", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[:500]
+    j = json.loads(lines[0])
+    assert j["config"]["delivery"] == "host" and "nccl, 1 ranks" in j["config"]["collective"]
+    assert j["hbm_ring"]["value"] > 1e6 and j["value"] > 1e6
+
+
+@pytest.mark.gpu
 def test_bench_json_contract():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--envs", "8192",
                         "--cpu-seconds", "0.5", "--nn-steps", "1"], capture_output=True, text=True, timeout=600)

@@ -98,10 +98,10 @@ def selectActionBatch(number_of_actions, epsilon, grid_shift, toric_size, state,
     persp, pos, counts = generatePerspectiveBatch(grid_shift, toric_size, state, device=dev)
     dev = persp.device
     n = int(counts.numel())
-    offsets = torch.zeros(n + 2, dtype=torch.int64, device=dev)[:n + 1]
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, 0, out=offsets[1:])
     q = _forward_chunked(model, persp, chunk)
-    eps = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(np.asarray(epsilon, np.float64), (n,))), device=dev)
+    eps = torch.as_tensor(np.array(np.broadcast_to(np.asarray(epsilon, np.float64), (n,))), device=dev)   # writable copy
     actions = torch.empty((n, 4), dtype=torch.int32, device=dev)
     qv = torch.empty((n, 3), dtype=torch.float32, device=dev)
     call = _select_rng["calls"]

@@ -169,57 +169,7 @@ static void t_stream_stack(int n, const uint8_t* st, const int64_t* offsets, uin
     }
 }
 
-// The stack through the WINDOWED flow of the stack-write kernel (PWindow): aligned windows of WINEL
-// elements over the whole stack; per window the lattices that overlap it, their tables, the in-window
-// hits emitted at margin-relative bit positions, then the window's bits read back.
-template <int D, int WINEL>
-static void t_window_stack(int n, const uint8_t* st, const int64_t* offsets, int64_t capacity, uint8_t* out, int32_t* pos) {
-    using L = Lat<D>;
-    using S = PStream<D>;
-    using PW = PWindow<D, WINEL>;
-    using B = typename L::B;
-    static uint32_t bits[PW::BUF_DW];
-    const int64_t p_cap = offsets[n] < capacity ? offsets[n] : capacity;
-    const int64_t total_el = p_cap * L::NQ;
-    const int64_t nwin = (total_el + WINEL - 1) / WINEL;
-    for (int64_t k = 0; k < nwin; ++k) {
-        const int64_t w0 = k * WINEL, w1 = w0 + WINEL < total_el ? w0 + WINEL : total_el;
-        for (int i = 0; i < PW::BUF_DW; ++i) bits[i] = 0;
-        for (int64_t e = PW::lattice_of(offsets, n, PW::first_persp(w0)); e < n; ++e) {
-            const int64_t off = offsets[e];
-            if (off * L::NQ >= w1) break;
-            B v, p, e0, e1, rv, rp;
-            pack_state<D>(st + (size_t)e * L::NQ, v, p);
-            L::hit_masks(v, p, e0, e1);
-            const int cnt = e0.popc() + e1.popc();
-            int64_t g_lo, g_hi;
-            PW::overlap(off, cnt, w0, w1, g_lo, g_hi);
-            if (g_hi <= g_lo) continue;
-            S::rotate_planes(v, p, rv, rp);
-            int hits[L::NQ], nh = 0;
-            for (int c = 0; c < L::NQ; ++c) if (c < L::DD ? e0.get(c) : e1.get(c - L::DD)) hits[nh++] = c;
-            for (int64_t g = g_lo; g < g_hi; ++g) {
-                const int h = hits[g - off], l = h >= L::DD, rem = h - l * L::DD;
-                int rs, cs;
-                S::hit_shifts(l, rem / D, rem % D, rs, cs);
-                const B ov = S::roll_cols_masked(L::roll_rows(l ? rv : v, rs), cs, L::lowcols(cs));
-                const B op = S::roll_cols_masked(L::roll_rows(l ? rp : p, rs), cs, L::lowcols(cs));
-                S::emit_at(PW::bit_of(g, w0), ov, op, [&](int idx, uint32_t val) { bits[idx] |= val; });
-                if (pos && g * L::NQ >= w0) { pos[3 * g] = l; pos[3 * g + 1] = rem / D; pos[3 * g + 2] = rem % D; }
-            }
-        }
-        for (int64_t x = w0; x < w1; ++x) out[x] = (uint8_t)(S::window(bits, (uint32_t)(PW::MARGIN_DW * 32 + (x - w0))) & 1u);
-    }
-}
-
 extern "C" {
-int shim_window_stack(int d, int winel, int n, const uint8_t* st, const int64_t* offsets, int64_t capacity, uint8_t* out,
-                      int32_t* pos) {
-#define C_(D) (winel == 2048 ? t_window_stack<D, 2048>(n, st, offsets, capacity, out, pos) \
-                             : t_window_stack<D, 8192>(n, st, offsets, capacity, out, pos))
-    DISPATCH(d, C_)
-#undef C_
-}
 int shim_stream_stack(int d, int n, const uint8_t* st, const int64_t* offsets, uint8_t* out) {
 #define C_(D) t_stream_stack<D>(n, st, offsets, out)
     DISPATCH(d, C_)

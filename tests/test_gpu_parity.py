@@ -271,17 +271,6 @@ def test_bad_actions_and_capacity_are_reported(T):
     with pytest.raises(T.ToricEnvError):
         gpu.check()
     gpu.check()                                            # latch is cleared by the read
-    # what fits is still written (the first `capacity` perspectives), nothing at or beyond the capacity
-    bp, _, _, _ = O.generate_perspective_batch(gpu.getStates().astype(np.uint8))
-    assert np.array_equal(small.cpu().numpy(), bp[:P - 1].astype(np.float32))
-    canary = torch.full(((P - 3) * 2 * d * d + 512,), 7.0, dtype=torch.float32, device=gpu.device)
-    pcan = torch.full(((P - 3) * 3 + 64,), -5, dtype=torch.int32, device=gpu.device)
-    gpu._call(gpu._L.tq_persp_write, off.data_ptr(), canary.data_ptr(), pcan.data_ptr(), P - 3, 0)
-    with pytest.raises(T.ToricEnvError):
-        gpu.check()
-    k = (P - 3) * 2 * d * d
-    assert np.array_equal(canary[:k].cpu().numpy(), bp[:P - 3].astype(np.float32).reshape(-1)) and bool((canary[k:] == 7).all())
-    assert bool((pcan[(P - 3) * 3:] == -5).all())
     gpu.close()
 
 

@@ -82,34 +82,6 @@ def test_perspective_bitstream_algebra(shim, d):
     assert np.array_equal(out, per)
 
 
-@pytest.mark.parametrize("winel", (2048, 8192))
-@pytest.mark.parametrize("d", SIZES)
-def test_windowed_stack_flow(shim, d, winel):
-    """PWindow: the whole stack cut into aligned windows (lattice lookup by binary search on the offsets,
-    overlap ranges, margin-relative emit, window read-back) reproduces the oracle's stack and positions,
-    also when the capacity cuts the stack short, with empty lattices in the batch, and with windows that
-    hold many small lattices (d=3) or a fraction of one (d=13)."""
-    rng = np.random.default_rng(400 + d)
-    n = 150
-    _, st = O.reset_lattices(5, np.arange(n), 0, 0.12, d)
-    st[30:60] = (rng.random((30, 2, d, d)) < 0.5)
-    st[60:70] = 0                                             # a run of empty lattices
-    st[0] = 0
-    st[n - 1] = 0
-    st[n - 2] = 1
-    per, pos, cnt, off = O.generate_perspective_batch(st)
-    P = per.shape[0]
-    for cap in (P + 5, P, P - 7, 3):
-        out = np.full(per.shape, 9, np.uint8)
-        opos = np.full((P, 3), -1, np.int32)
-        assert shim.shim_window_stack(d, winel, n, P(st) if False else st.ctypes.data_as(C.c_void_p),
-                                      off.ctypes.data_as(C.c_void_p), C.c_int64(cap), out.ctypes.data_as(C.c_void_p),
-                                      opos.ctypes.data_as(C.c_void_p)) == 0
-        k = min(cap, P)
-        assert np.array_equal(out[:k], per[:k]) and np.array_equal(opos[:k], pos[:k])
-        assert (out[k:] == 9).all() and (opos[k:] == -1).all()  # nothing at or beyond the capacity
-
-
 @pytest.mark.parametrize("d", SIZES)
 def test_reset_matches_oracle(shim, d):
     rng = np.random.default_rng(100 + d)

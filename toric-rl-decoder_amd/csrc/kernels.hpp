@@ -927,213 +927,6 @@ __global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restr
     if (e < N) persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, tables[wave], err, lane);
 }
 
-// ------------------------------------------------------------------ stack write, windowed form
-// The whole stack (element index x = perspective * NQ + cell over ALL lattices) is cut into aligned
-// windows of WINEL elements (32 KB of f32 / bf16 output, 16 KB of u8).  Persistent wavefronts walk the
-// windows grid-stride: window k needs the lattice that holds its first perspective (win_lat[k], one
-// binary search per window in k_window_index), then builds the window's WINEL stream bits in an LDS
-// buffer exactly like persp_lattice does for a whole lattice (tables per overlapping lattice, one
-// lane per in-window hit, ds_or_b32 at margin-relative bit positions) and expands them with 16-byte
-// stores.  Why this shape (tools/membench18.hip, profiles/r02_membench18_*): with the real loop body a
-// wave that streams through aligned 32 KB windows reaches 6.1-6.6 TB/s where one wave per variable
-// segment reaches 5.2-5.8, and every microsecond a wave spends in set-up instead of storing costs
-// bandwidth -- so the set-up of window k+1 (into the other LDS buffer) is INTERLEAVED with the stores of
-// window k: after every phase of the set-up the wave issues the next batch of stores of the current
-// window (`pump`), and flushes what is left when the set-up is done.  No line of the stack is shared
-// between two waves (windows are multiples of 128 bytes), so the ownership rule of the per-lattice
-// form and its mixed-line code are not needed.
-template <int D, typename OutT>
-struct WinCfg {
-    static constexpr int VEC = 16 / (int)sizeof(OutT);
-    static constexpr int WINEL = sizeof(OutT) == 4 ? 8192 : 16384;       // elements = stream bits per window
-    static constexpr int ITERS = WINEL / (64 * VEC);                      // 1 KiB wave stores per window: 32 / 32 / 16
-    static constexpr int PUMP = 8;                                        // stores issued between two set-up phases
-    using PW = PWindow<D, WINEL>;
-};
-
-template <int D, typename OutT>
-struct WinLds {
-    using C = WinCfg<D, OutT>;
-    static constexpr int NQP = (Lat<D>::NQ + 7) & ~7;
-    __attribute__((aligned(16))) uint32_t bits[2][C::PW::BUF_DW];         // double buffer: window being stored / being built
-    uint64_t rr[4][D][Lat<D>::W];
-    uint64_t low[D][Lat<D>::W];
-    uint8_t hits[NQP];
-};
-
-// win_lat[k] = lattice holding the first perspective of window k (only windows that start inside the stack)
-template <int D>
-__global__ __launch_bounds__(256) void k_window_index(const int64_t* __restrict__ offsets, int64_t N, int64_t capacity,
-                                                      int winel, int32_t* __restrict__ win_lat, int64_t nwin_max) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nwin_max) return;
-    const int64_t p_total = offsets[N];
-    const int64_t p_cap = p_total < capacity ? p_total : capacity;
-    const int64_t w0 = k * winel;
-    if (w0 >= p_cap * Lat<D>::NQ) return;
-    win_lat[k] = (int32_t)PWindow<D, 8192>::lattice_of(offsets, N, w0 / Lat<D>::NQ);
-}
-
-// stores of the window whose bits sit in `buf`: iteration `it` writes groups it*64 + lane
-template <int D, typename OutT>
-struct WinPump {
-    using C = WinCfg<D, OutT>;
-    const uint32_t* bp;        // this lane's first window dword (margin and lane offset applied)
-    char* seg;                 // wave-uniform base of the window in the output
-    int n_groups;              // whole 16-byte groups of the window that lie inside the stack
-    int it;                    // next iteration (wave-uniform)
-    uint32_t ph;
-    int lane;
-    __device__ __forceinline__ void init(const uint32_t* buf, OutT* out, int64_t w0, int64_t w1, int lane_) {
-        lane = lane_;
-        const uint32_t rel0 = (uint32_t)C::PW::MARGIN_DW * 32u + (uint32_t)lane * C::VEC;
-        ph = rel0 & 31u;
-        bp = buf + (rel0 >> 5);
-        seg = reinterpret_cast<char*>(out + w0);
-        n_groups = (int)((w1 - w0) / C::VEC);
-        it = 0;
-    }
-    __device__ __forceinline__ void run(int count) {
-        const int end = it + count < C::ITERS ? it + count : C::ITERS;
-        for (; it < end; ++it) {
-            const int g = it * 64 + lane;
-            const uint32_t* q = bp + it * (2 * C::VEC);
-            const uint32_t wb = (uint32_t)(((((uint64_t)q[1]) << 32) | q[0]) >> ph);
-            if (g < n_groups) *reinterpret_cast<u32x4*>(seg + (uint32_t)g * 16u) = expand_bits<OutT>(wb);
-        }
-    }
-    __device__ __forceinline__ void flush() { run(C::ITERS); }
-};
-
-template <int D, typename OutT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_persp_write_win(const uint64_t* __restrict__ vp, int64_t N,
-                                                         const int64_t* __restrict__ offsets,
-                                                         const int32_t* __restrict__ win_lat, OutT* __restrict__ out,
-                                                         int32_t* __restrict__ pos, int64_t capacity, int* __restrict__ err,
-                                                         int dbg) {
-    using L = Lat<D>;
-    using S = PStream<D>;
-    using C = WinCfg<D, OutT>;
-    using PW = typename C::PW;
-    using Enc = OutEnc<OutT>;
-    constexpr int DD = L::DD, NQ = L::NQ, W = L::W, WINEL = C::WINEL;
-    __shared__ WinLds<D, OutT> lds[4];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    WinLds<D, OutT>& t = lds[wave];
-
-    const int64_t p_total = offsets[N];
-    const int64_t p_cap = p_total < capacity ? p_total : capacity;       // nothing is written at or beyond the capacity
-    if (p_total > capacity && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, ERR_CAPACITY);
-    const int64_t total_el = p_cap * NQ;
-    const int64_t nwin = (total_el + WINEL - 1) / WINEL;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    int64_t k = (int64_t)blockIdx.x * 4 + wave;
-    if (k >= nwin) return;
-
-    if (lane < D) {                                          // column masks: once per wave
-        const typename L::B m = L::lowcols(lane);
-#pragma unroll
-        for (int w = 0; w < W; ++w) t.low[lane][w] = m.w[w];
-    }
-
-    // builds the stream bits of window kk in buffer b; `pump(n)` issues up to n stores of the window in flight
-    auto build = [&](int64_t kk, int b, auto&& pump) {
-        if (dbg & 4) return;                                 // experiment: no build at all (garbage bits)
-        uint32_t* __restrict__ buf = t.bits[b];
-        const int64_t w0 = kk * WINEL, w1 = w0 + WINEL < total_el ? w0 + WINEL : total_el;
-        {
-            uint4* b4 = reinterpret_cast<uint4*>(buf);
-            for (int i = lane; i < PW::BUF_DW / 4; i += 64) b4[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        for (int64_t e = __builtin_amdgcn_readfirstlane(win_lat[kk]); e < N; ++e) {
-            const int64_t off = offsets[e];
-            if (off * NQ >= w1) break;
-            typename L::B v, p, e0, e1;
-#pragma unroll
-            for (int w = 0; w < W; ++w) { v.w[w] = vp[(int64_t)w * N + e]; p.w[w] = vp[((int64_t)W + w) * N + e]; }
-            L::hit_masks(v, p, e0, e1);
-            const int n0 = e0.popc();
-            const int n = n0 + e1.popc();
-            int64_t g_lo, g_hi;
-            PW::overlap(off, n, w0, w1, g_lo, g_hi);
-            if (g_hi <= g_lo) continue;
-            // ---- tables of this lattice: rotated planes (ballot), row-rolled planes, hit list
-            typename L::B rv, rp;
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const int o = 64 * w + lane;
-                const bool in = o < DD;
-                const int oc = in ? o : 0;
-                rv.w[w] = __ballot(in && v.get(S::rot_src_v(oc)));
-                rp.w[w] = __ballot(in && p.get(S::rot_src_p(oc)));
-            }
-            wave_lds_sync();                                 // the previous lattice's hit lanes are done with the tables
-            if (lane < 4 * D) {
-                const int sel = lane / D, kr = lane - sel * D;
-                typename L::B src;
-#pragma unroll
-                for (int w = 0; w < W; ++w) src.w[w] = sel == 0 ? v.w[w] : (sel == 1 ? p.w[w] : (sel == 2 ? rv.w[w] : rp.w[w]));
-                const typename L::B r = (src.shl(kr * D) | src.shr(DD - kr * D)) & L::full();
-#pragma unroll
-                for (int w = 0; w < W; ++w) t.rr[sel][kr][w] = r.w[w];
-            }
-            for (int c = lane; c < NQ; c += 64) {
-                const int l = c >= DD, bit = c - l * DD;
-                if (l ? e1.get(bit) : e0.get(bit)) t.hits[l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint8_t)c;
-            }
-            wave_lds_sync();
-            pump(C::PUMP);
-            // ---- one lane per in-window hit
-            const int k_lo = (int)(g_lo - off), k_hi = (int)(g_hi - off);
-            for (int kh = k_lo + lane; kh < k_hi; kh += 64) {
-                const int h = t.hits[kh];
-                const int layer = h >= DD, rem = h - layer * DD, i = rem / D, j = rem - i * D;
-                int rs, cs;
-                S::hit_shifts(layer, i, j, rs, cs);
-                typename L::B a, c2, low;
-#pragma unroll
-                for (int w = 0; w < W; ++w) { a.w[w] = t.rr[2 * layer][rs][w]; c2.w[w] = t.rr[2 * layer + 1][rs][w]; low.w[w] = t.low[cs][w]; }
-                const typename L::B ov = S::roll_cols_masked(a, cs, low), op = S::roll_cols_masked(c2, cs, low);
-                const int64_t g = off + kh;
-                S::emit_at(PW::bit_of(g, w0), ov, op, [&](int idx, uint32_t val) { atomicOr(&buf[idx], val); });
-                if (pos != nullptr && g * NQ >= w0 && !(dbg & 2)) {        // a perspective's position is written by the window it starts in
-                    int32_t* pp = pos + 3 * g;
-                    pp[0] = layer; pp[1] = i; pp[2] = j;
-                }
-            }
-            pump(C::PUMP);
-        }
-        wave_lds_sync();
-    };
-    // the few elements past the last whole 16-byte group of the stack (total_el is not a multiple of VEC)
-    auto tail = [&](int64_t kk, int b) {
-        const int64_t w0 = kk * WINEL, w1 = w0 + WINEL < total_el ? w0 + WINEL : total_el;
-        const int valid = (int)(w1 - w0), done = valid / C::VEC * C::VEC;
-        if (done + lane < valid) {
-            const uint32_t bit = S::window(t.bits[b], (uint32_t)PW::MARGIN_DW * 32u + (uint32_t)(done + lane)) & 1u;
-            const uint32_t val = (0u - bit) & Enc::ONE;
-            if (Enc::BITS == 32) reinterpret_cast<uint32_t*>(out)[w0 + done + lane] = val;
-            else if (Enc::BITS == 16) reinterpret_cast<uint16_t*>(out)[w0 + done + lane] = (uint16_t)val;
-            else reinterpret_cast<uint8_t*>(out)[w0 + done + lane] = (uint8_t)val;
-        }
-    };
-
-    int b = 0;
-    build(k, b, [](int) {});
-    for (;;) {
-        const int64_t w0 = k * WINEL, w1 = w0 + WINEL < total_el ? w0 + WINEL : total_el;
-        WinPump<D, OutT> pump;
-        pump.init(t.bits[b], out, w0, w1, lane);
-        const int64_t kn = k + nwaves;
-        if (kn < nwin) build(kn, b ^ 1, [&](int cnt) { if (!(dbg & 1)) pump.run(cnt); });
-        pump.flush();
-        if (w1 == total_el) tail(k, b);
-        if (kn >= nwin) break;
-        k = kn;
-        b ^= 1;
-    }
-}
-
 // generateTransitionParallel on explicit u8 grids: one thread per output byte, the (hit, cell)
 // -> source-cell table does shift_state + rotate_state in one lookup; loads and stores coalesced.
 template <int D>

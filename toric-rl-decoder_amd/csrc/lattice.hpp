@@ -286,10 +286,8 @@ struct PStream {
     }
     // OR the string of perspective `pidx` into the lattice's bitstream: orfn(dword index, value)
     template <class OrFn>
-    TQ_HD static void emit(int pidx, const B& ov, const B& op, OrFn&& orfn) { emit_at((uint32_t)pidx * NQ, ov, op, orfn); }
-    // the same at an arbitrary bit position of a buffer (ND + 1 dwords are touched from pos / 32 on)
-    template <class OrFn>
-    TQ_HD static void emit_at(uint32_t pos, const B& ov, const B& op, OrFn&& orfn) {
+    TQ_HD static void emit(int pidx, const B& ov, const B& op, OrFn&& orfn) {
+        const uint32_t pos = (uint32_t)pidx * NQ;
         const int base = (int)(pos >> 5), sh = (int)(pos & 31);
         uint32_t prev = 0;
 #pragma unroll
@@ -303,41 +301,6 @@ struct PStream {
     TQ_HD static uint32_t window(const uint32_t* bits, uint32_t rel) {
         const uint32_t idx = rel >> 5, ph = rel & 31;
         return (uint32_t)(((((uint64_t)bits[idx + 1]) << 32) | bits[idx]) >> ph);
-    }
-};
-
-// ------------------------------------------------------------------ windows of the perspective stack
-// The stack-write kernel cuts the WHOLE stack (all lattices, element index x = perspective * NQ + cell)
-// into aligned windows of WINEL elements; one wavefront builds the WINEL stream bits of a window in an
-// LDS buffer and expands them.  Buffer layout (dwords): [ND margin | WINEL/32 window bits | ND + 2 margin]:
-// the first / last perspective of a window usually straddles its border and simply spills into the
-// margins.  Everything here is plain index arithmetic shared by the kernel and the host test.
-template <int D, int WINEL>
-struct PWindow {
-    using S = PStream<D>;
-    static constexpr int NQ = S::NQ, ND = S::ND;
-    static constexpr int MARGIN_DW = ND;                                   // >= NQ bits
-    static constexpr int BUF_DW = (MARGIN_DW + WINEL / 32 + ND + 2 + 3) & ~3;
-    static_assert(WINEL % 2048 == 0, "a window is a whole number of 1 KiB wave stores for every element size");
-
-    // first perspective that has an element in the window starting at element w0
-    TQ_HD static int64_t first_persp(int64_t w0) { return w0 / NQ; }
-    // perspectives [g_lo, g_hi) of a lattice (global perspective numbers off .. off+n) that overlap [w0, w1)
-    TQ_HD static void overlap(int64_t off, int n, int64_t w0, int64_t w1, int64_t& g_lo, int64_t& g_hi) {
-        const int64_t pf = w0 / NQ, pl = (w1 + NQ - 1) / NQ;               // [pf, pl) = perspectives touching the window
-        g_lo = off > pf ? off : pf;
-        g_hi = off + n < pl ? off + n : pl;
-    }
-    // bit position, inside the buffer, of element 0 of global perspective g (window starts at element w0)
-    TQ_HD static uint32_t bit_of(int64_t g, int64_t w0) { return (uint32_t)((int64_t)MARGIN_DW * 32 + (g * NQ - w0)); }
-    // lattice that contains perspective p: offsets[e] <= p < offsets[e+1]  (offsets[0] = 0 <= p < offsets[N])
-    TQ_HD static int64_t lattice_of(const int64_t* offsets, int64_t N, int64_t p) {
-        int64_t lo = 0, hi = N;
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (offsets[mid] <= p) lo = mid; else hi = mid;
-        }
-        return lo;
     }
 };
 

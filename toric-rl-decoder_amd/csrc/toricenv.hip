@@ -132,64 +132,29 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
     return TQ_OK;
 }
 
-// TORIC_PERSP_KERNEL=lattice selects the one-wave-per-lattice form of the stack write (kept for A/B
-// measurement); the default is the windowed form (kernels.hpp).
-bool use_lattice_kernel() {
-    static const bool v = [] { const char* e = getenv("TORIC_PERSP_KERNEL"); return e && !strcmp(e, "lattice"); }();
-    return v;
-}
-
-// entries the window index needs for n lattices of size d (smallest window: 8192 elements)
-size_t win_index_entries(int d, int64_t n) {
-    const int64_t nq = 2 * (int64_t)d * d;
-    return (size_t)((n * nq * nq + 8191) / 8192 + 2);
-}
-
-struct WriteArgs {
-    const uint64_t* vp; int64_t n; const int64_t* offsets; void* out; int32_t* pos; int64_t capacity;
-    int32_t* win_lat; int num_cus; int* err; hipStream_t stream;
-};
-
 template <int D, typename OutT>
-int launch_persp_write_t(const WriteArgs& a) {
-    if (use_lattice_kernel()) {
-        // One lattice per wave; the hardware dispatcher balances the variable-size lattices.
-        const int64_t blocks = (a.n + 3) / 4;
-        hipLaunchKernelGGL((tq::k_persp_write<D, OutT, 256>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.vp, a.n,
-                           a.offsets, (OutT*)a.out, a.pos, a.capacity, a.err);
-        KCHECK();
-        return TQ_OK;
-    }
-    using C = tq::WinCfg<D, OutT>;
-    constexpr int64_t NQ = tq::Lat<D>::NQ;
-    const int64_t max_p = a.capacity < a.n * NQ ? a.capacity : a.n * NQ;              // the stack cannot be longer than this
-    const int64_t nwin_max = (max_p * NQ + C::WINEL - 1) / C::WINEL;
-    if (nwin_max == 0) return TQ_OK;
-    hipLaunchKernelGGL(tq::k_window_index<D>, grid1(nwin_max, 256), dim3(256), 0, a.stream, a.offsets, a.n, a.capacity,
-                       (int)C::WINEL, a.win_lat, nwin_max);
-    // persistent waves: exactly as many workgroups as are resident at once (a workgroup that had to wait for a
-    // slot would run its whole share of windows after everyone else); window k goes to wave k mod (4 * blocks)
-    static const int per_cu = [] {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tq::k_persp_write_win<D, OutT>, 256, 0) != hipSuccess || nb < 1) nb = 4;
-        return nb > 8 ? 8 : nb;                              // 32 waves per CU at most
-    }();
-    int64_t blocks = (nwin_max + 3) / 4;
-    if (blocks > (int64_t)a.num_cus * per_cu) blocks = (int64_t)a.num_cus * per_cu;
-    hipLaunchKernelGGL((tq::k_persp_write_win<D, OutT>), dim3((unsigned)blocks), dim3(256), 0, a.stream, a.vp, a.n, a.offsets,
-                       (const int32_t*)a.win_lat, (OutT*)a.out, a.pos, a.capacity, a.err,
-                       getenv("TORIC_WIN_FLAGS") ? atoi(getenv("TORIC_WIN_FLAGS")) : 0);
+int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
+                         int64_t capacity, int* err, hipStream_t stream) {
+    constexpr int THREADS = 256;                             // waves of a workgroup share nothing: no barrier, no common table
+    constexpr int WAVES = THREADS / 64;
+    // One lattice per wave; the hardware dispatcher balances the variable-size lattices.  Persistent
+    // waves (static, or drawing tickets), fixed aligned windows and cooperative workgroups were all
+    // built or prototyped and are slower or equal in the real kernel (git history).
+    const int64_t blocks = (n + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL((tq::k_persp_write<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
+                       offsets, (OutT*)out, pos, capacity, err);
     KCHECK();
     return TQ_OK;
 }
 
 template <int D>
-int launch_persp_write(const WriteArgs& a, int dtype) {
+int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
+                       int64_t capacity, int dtype, int* err, hipStream_t stream) {
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(a);
-        case TQ_F16: return launch_persp_write_t<D, __half>(a);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(a);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(a);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -216,7 +181,6 @@ struct tq_env {
     uint32_t* mark;        // [N] epoch of the last indexed reset that touched the lattice (duplicate detection)
     uint32_t reset_epoch;
     void* tblock;          // packed block of N slots: scratch of tq_transition_write
-    int32_t* win_lat;      // window index of the stack write (k_window_index)
     const uint8_t* lut;
     int num_cus;
 };
@@ -286,7 +250,6 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc((void**)&h->err, 4);
     alloc((void**)&h->mark, N * 4);
     alloc(&h->tblock, (size_t)tq::block_bytes(h->w, n_envs));
-    alloc((void**)&h->win_lat, 4 * win_index_entries(d, n_envs));
     h->reset_epoch = 0;
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
@@ -299,7 +262,7 @@ int tq_destroy(tq_env* h) {
     if (!h) return TQ_OK;
     DeviceGuard guard;
     (void)guard.enter_device(h->device);
-    (void)hipFree(h->mark); (void)hipFree(h->tblock); (void)hipFree(h->win_lat);
+    (void)hipFree(h->mark); (void)hipFree(h->tblock);
     (void)hipFree(h->planes); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
     (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->err);
     delete h;
@@ -479,8 +442,7 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
     REQUIRE_ALIGNED16(out, "out");
     REQUIRE_ALIGNED16(positions, "positions");
     const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
-    const WriteArgs wa{vp, h->n, offsets, out, positions, capacity, h->win_lat, h->num_cus, h->err, stream};
-#define CALL(D) if (int rc = launch_persp_write<D>(wa, dtype)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream)) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;
@@ -490,8 +452,8 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
 static size_t states_scratch_bytes(int d, int64_t n) {
     const size_t w = (size_t)(d * d + 63) / 64;
     const size_t cnt_bytes = (((size_t)n * 4 + 32 + 15) & ~(size_t)15);
-    const size_t part_bytes = ((((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8 + 15) & ~(size_t)15;
-    return 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes + 4 * win_index_entries(d, n);
+    const size_t part_bytes = (((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8;
+    return 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes;
 }
 
 // set-up call: allocates (and synchronises); the tq_states_persp_* calls themselves never allocate
@@ -516,8 +478,7 @@ int tq_states_reserve(int d, int n_max) {
     return TQ_OK;
 }
 
-static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int32_t** win_lat,
-                          int** err) {
+static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int** err) {
     DeviceCtx& c = g_ctx[dev];
     std::lock_guard<std::mutex> lock(c.mu);
     const size_t w = (size_t)(d * d + 63) / 64;
@@ -527,8 +488,6 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
     *vp = (uint64_t*)c.ws;
     *counts = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8);
     *partial = (int64_t*)((char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes);
-    const size_t part_bytes = ((((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8 + 15) & ~(size_t)15;
-    *win_lat = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes);
     *err = c.err;
     return TQ_OK;
 }
@@ -543,8 +502,8 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut_unused;
     if (int rc = get_lut(dev, d, stream, &lut_unused)) return rc;
-    uint64_t* vp; int32_t* cnt; int64_t* part; int32_t* wl; int* err;
-    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &wl, &err)) return rc;
+    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
 #define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, cnt, (int64_t)n)
     DISPATCH_D(d, CALL)
 #undef CALL
@@ -564,14 +523,13 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut;
     if (int rc = get_lut(dev, d, stream, &lut)) return rc;
-    uint64_t* vp; int32_t* cnt; int64_t* part; int32_t* wl; int* err;
-    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &wl, &err)) return rc;
+    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
 #define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, (int32_t*)nullptr, (int64_t)n)
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-    const WriteArgs wa{vp, n, offsets, out, positions, capacity, wl, g_ctx[dev].num_cus, err, stream};
-#define CALL(D) if (int rc = launch_persp_write<D>(wa, dtype)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, err, stream)) return rc
     DISPATCH_D(d, CALL)
 #undef CALL
     return TQ_OK;

@@ -71,6 +71,10 @@ def parse(argv=None):
     ap.add_argument("--delivery", default="auto", choices=["auto", "host", "hbm"],
                     help="N>1: where gathered transition blocks end up. host = pinned host replay ring (default for "
                          "N>1, north_star), hbm = ring in rank 0's HBM only")
+    ap.add_argument("--roots", type=int, default=0,
+                    help="N>1: ranks that take turns as root of the transition gather, each draining to the host over "
+                         "its own PCIe link (0 = auto: 2 from 8 ranks on, where one Gen5 x16 link no longer carries "
+                         "the ~63 GB/s of packed records; 1 below)")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--nn-steps", type=int, default=1,
@@ -290,6 +294,8 @@ def main():
         K = max(flush, K - K % flush)                                  # whole replays
         W = max(flush, W - W % flush)
     host_delivery = dist_on and not args.no_transitions and args.delivery in ("auto", "host") and backend == "nccl"
+    roots = args.roots if args.roots > 0 else (2 if world >= 8 else 1)
+    roots = max(1, min(roots, world))
 
     def make_model():
         from toric_rl_decoder_amd.policy import NN_11
@@ -327,7 +333,7 @@ def main():
     def make_gathers(host):
         if not (dist_on and have_blocks):
             return None
-        return [G.TransitionGather(sh.blocks[0].nbytes, device, ring_slots=2, host_drain=host) for sh in shards]
+        return [G.TransitionGather(sh.blocks[0].nbytes, device, ring_slots=2, host_drain=host, roots=roots) for sh in shards]
 
     tg = make_gathers(host_delivery)
     state = {"tg": tg, "model": model}
@@ -505,9 +511,9 @@ def main():
         cfg_name = "configs[2]" if (world == 1 and n == ENVS_N1) else ("configs[4] shape" if n == ENVS_MULTI else "custom")
         collective = None
         if dist_on:
-            collective = "transition gather (packed blocks incl. priorities) to rank 0 (%s, %d ranks) every %d steps%s" % (
-                backend, dist.get_world_size(), flush,
-                " + D2H drain of every gathered slot to the pinned host replay ring" if host_delivery else "; ring in rank 0's HBM")
+            collective = "transition gather (packed blocks incl. priorities) to %s (%s, %d ranks) every %d steps%s" % (
+                "rank 0" if roots == 1 else "ranks 0..%d in turn" % (roots - 1), backend, dist.get_world_size(), flush,
+                " + D2H drain of every gathered slot to the root's pinned host replay ring" if host_delivery else "; ring in the root's HBM")
         res = {
             "metric": "env steps/sec (batched) at d=%d p=%g" % (d, args.p_error),
             "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -521,6 +527,7 @@ def main():
                        "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
                        "streams_per_gpu": S, "hip_graph": bool(args.graph), "parallelism": "env-shard x%d" % world,
                        "steady_state": not args.no_burn_in, "delivery": ("host" if host_delivery else "hbm") if dist_on else None,
+                       "gather_roots": roots if dist_on else None,
                        "collective": collective},
             "perspectives_per_sec": float(p_sum.item()) / elapsed,
             "perspectives_per_lattice": float(p_sum.item()) / total_steps,

@@ -55,13 +55,14 @@ def test_bench_two_ranks_share_the_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "8",
-                        "--envs", "4096", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, env=env)
+                        "--envs", "4096", "--cpu-seconds", "0", "--roots", "2"], capture_output=True, text=True, timeout=900,
+                       env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["envs_per_gpu"] == 4096
-    assert "2 ranks" in j["config"]["collective"] and j["value"] > 1e6
+    assert "2 ranks" in j["config"]["collective"] and j["value"] > 1e6 and j["config"]["gather_roots"] == 2
     assert abs(j["value"] - 2 * 4096 * 16 / (j["ms_per_step"] * 16e-3)) / j["value"] < 1e-6
 
 

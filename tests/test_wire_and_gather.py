@@ -91,6 +91,49 @@ def _free_port():
     return port
 
 
+def _worker_two_roots(rank, world, port, d, n, q):
+    """roots=2: flush i lands on rank i % 2; five flushes, two ring slots per root."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nbytes = wire.block_bytes(d, n)
+        g = gather.TransitionGather(nbytes, "cpu", ring_slots=2, roots=2)
+        where = []
+        for flush in range(5):
+            per, nper, act, rew, term = make_transitions(d, n, 10 * flush + rank)
+            buf = torch.from_numpy(wire.encode(d, per, nper, act, rew, term, priority=make_priorities(n, 10 * flush + rank)))
+            slot = g.gather(buf)
+            where.append((g.last_root, slot))
+        g.wait()
+        ok = where == [(0, 0), (1, 0), (0, 1), (1, 1), (0, 0)] and g.is_root
+        # what each root's ring holds at the end: rank 0 has flushes 4 (slot 0) and 2 (slot 1); rank 1 has 1 and 3
+        mine = {0: ((0, 4), (1, 2)), 1: ((0, 1), (1, 3))}[rank]
+        for slot, flush in mine:
+            for r in range(world):
+                per, nper, act, rew, term = make_transitions(d, n, 10 * flush + r)
+                out = wire.decode(g.slot_view(slot, r).numpy(), d, n)
+                ok &= np.array_equal(out["perspective"], per) and np.array_equal(out["action"], act)
+                ok &= np.array_equal(out["priority"].view(np.uint32), make_priorities(n, 10 * flush + r).view(np.uint32))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transition_gather_two_roots_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_roots, args=(r, 2, port, 5, 40, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
 def _worker(rank, world, port, d, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -914,8 +914,11 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     if (p_lane && y < p_limit) pos[y] = pval;
 }
 
+// SGPRs capped at 80: up to 80 a CU admits 8 of these workgroups (32 waves); the d >= 9 instantiations would
+// otherwise take 87-98 and lose one or two (MI355X_MICROARCH.md, residency), and the bandwidth of this kernel
+// follows the number of waves that are storing.
 template <int D, typename OutT, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_persp_write(const uint64_t* __restrict__ vp, int64_t N,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_persp_write(const uint64_t* __restrict__ vp, int64_t N,
                                                          const int64_t* __restrict__ offsets, OutT* __restrict__ out,
                                                          int32_t* __restrict__ pos, int64_t capacity, int* __restrict__ err) {
     constexpr int WAVES = THREADS / 64;

@@ -22,14 +22,21 @@ def shard_range(total_envs, world_size, rank):
 
 
 class TransitionGather:
-    """Gathers equal-size byte blocks from every rank into a ring of `ring_slots` slots on rank 0.
+    """Gathers equal-size byte blocks from every rank into rings of `ring_slots` slots on the root rank(s).
 
     ``gather(buf)`` enqueues the exchange of this flush's block (async on the collective's own
     stream for nccl, so it overlaps the next env steps) and returns the ring slot it lands in;
     ``wait()`` blocks until every outstanding exchange has completed.
+
+    The caller alternates between ``source_buffers`` blocks (default 2).
+    ``roots`` > 1: flush i is gathered to rank ``i % roots`` -- every root keeps its own ring and, with
+    ``host_drain``, drains it to its own pinned host ring over its own PCIe link (one Gen5 x16 link
+    carries ~55 GB/s; eight ranks of BASELINE configs[4] produce ~63 GB/s of packed records).  The
+    host replay buffer is then the union of the roots' pinned rings.  ``last_root`` names the root of
+    the most recent gather.
     """
 
-    def __init__(self, block_nbytes, device, ring_slots=2, group=None, host_drain=False):
+    def __init__(self, block_nbytes, device, ring_slots=2, group=None, host_drain=False, roots=1, source_buffers=2):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -38,8 +45,10 @@ class TransitionGather:
         self.device = torch.device(device)
         self.stage_device = self.device if self.backend == "nccl" else torch.device("cpu")
         self.ring_slots = int(ring_slots)
+        self.roots = max(1, min(int(roots), self.world))
+        self.is_root = self.rank < self.roots
         self.ring = None
-        if self.rank == 0:
+        if self.is_root:
             self.ring = torch.zeros((self.ring_slots, self.world, self.nbytes), dtype=torch.uint8,
                                     device=self.stage_device)
         # optional drain to the host replay process: every gathered slot is copied to a pinned host
@@ -48,31 +57,39 @@ class TransitionGather:
         self.host_ring = None
         self._copy_stream = None
         self._drained = []
-        if host_drain and self.rank == 0 and self.stage_device.type == "cuda":
+        if host_drain and self.is_root and self.stage_device.type == "cuda":
             self.host_ring = torch.empty((self.ring_slots, self.world, self.nbytes), dtype=torch.uint8).pin_memory()
             self._copy_stream = torch.cuda.Stream(device=self.device)
             self._drained = [torch.cuda.Event() for _ in range(self.ring_slots)]
         self._next = 0
         self._pending = []
+        self.last_root = 0
+        # exchanges that may be in flight after gather() returns: the caller rotates `source_buffers` blocks
+        # (one is being filled while the others are being sent), and a ring slot of a root is re-used
+        # ring_slots * roots flushes later
+        self._max_pending = max(0, min(int(source_buffers) - 1, self.ring_slots * self.roots - 1))
 
     def gather(self, buf):
         if buf.dtype != torch.uint8 or buf.numel() != self.nbytes:
             raise ValueError("block must be a uint8 tensor of block_nbytes elements")
-        slot = self._next % self.ring_slots
+        root = self._next % self.roots
+        use = self._next // self.roots                      # how many flushes this root has received before
+        slot = use % self.ring_slots
         self._next += 1
+        self.last_root = root
+        mine = self.rank == root
         src = buf if buf.device == self.stage_device else buf.to(self.stage_device)
-        outs = [self.ring[slot, r] for r in range(self.world)] if self.rank == 0 else None
-        if self.host_ring is not None and self._next > self.ring_slots:
+        outs = [self.ring[slot, r] for r in range(self.world)] if mine else None
+        if mine and self.host_ring is not None and use >= self.ring_slots:
             torch.cuda.current_stream(self.device).wait_event(self._drained[slot])   # slot still being copied out?
-        work = dist.gather(src, gather_list=outs, dst=0, group=self.group, async_op=True)
+        work = dist.gather(src, gather_list=outs, dst=root, group=self.group, async_op=True)
         self._pending.append((work, src))
-        if self.host_ring is not None:
+        if mine and self.host_ring is not None:
             with torch.cuda.stream(self._copy_stream):
                 work.wait()                                     # copy stream waits for the collective, not the host
                 self.host_ring[slot].copy_(self.ring[slot], non_blocking=True)
                 self._drained[slot].record(self._copy_stream)
-        if len(self._pending) >= self.ring_slots:          # never overwrite a slot still in flight
-            self._drain(1)
+        self._drain(self._max_pending)                      # never overwrite a slot or a source block still in flight
         return slot
 
     def _drain(self, keep):

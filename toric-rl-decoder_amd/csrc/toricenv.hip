@@ -135,7 +135,10 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, int* err, hipStream_t stream) {
-    constexpr int THREADS = 256;                             // waves of a workgroup share nothing: no barrier, no common table
+    // One wave per workgroup: the waves share nothing (no barrier, no common table), and a wave that has
+    // finished its lattice is replaced at once instead of waiting for the slowest of four (lattices differ
+    // by +-30 % in size): +1 % over 256-thread workgroups, 4 of 4 alternating runs (profiles/r02_wg_size_and_gate.txt).
+    constexpr int THREADS = 64;
     constexpr int WAVES = THREADS / 64;
     // One lattice per wave; the hardware dispatcher balances the variable-size lattices.  Persistent
     // waves (static, or drawing tickets), fixed aligned windows and cooperative workgroups were all

@@ -79,6 +79,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--nn-steps", type=int, default=1,
                     help="N=1: timed steps of the NN_11-in-the-loop leg (configs[2] as written); 0 = skip")
+    ap.add_argument("--no-shard-leg", action="store_true",
+                    help="N=1: skip the extra timing of the N>1 per-GPU shape (131072 lattices); profiling runs use this "
+                         "so that every k_persp_write launch of the process has the headline shape")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
     ap.add_argument("--graph", action="store_true",
                     help="capture --flush steps in a HIP graph and replay it (launch-bound small batches; implies "
@@ -468,7 +471,7 @@ def main():
 
     # ---- N=1 on the default shape: one GPU on the per-GPU shape of the N>1 runs (configs[4]), like for like
     shard_leg = None
-    if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore":
+    if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore" and not args.no_shard_leg:
         k2, w2 = max(8, min(K, 40)), 8
         dt2, P2 = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,

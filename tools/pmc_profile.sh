@@ -7,7 +7,7 @@ OUT=$(realpath -m "$1"); shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --cpu-seconds 0 --nn-steps 0 --no-events $*"
+ARGS="--steps 10 --warmup 2 --cpu-seconds 0 --nn-steps 0 --no-shard-leg --no-events $*"
 pass() {
   name=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1 || echo "pass $name failed"

@@ -17,7 +17,7 @@ echo "[$TAG] plain bench"
 python3 bench.py "$@" > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "[$TAG] kernel trace"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" "$@" --cpu-seconds 0 --nn-steps 0 \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" "$@" --cpu-seconds 0 --nn-steps 0 --no-shard-leg \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 rm -rf "$OUT/trace"

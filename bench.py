@@ -67,6 +67,9 @@ def parse(argv=None):
     ap.add_argument("--out-dtype", default="f32", choices=["f32", "f16", "bf16", "u8"])
     ap.add_argument("--flush", type=int, default=8, help="steps per transition block / priorities / gather")
     ap.add_argument("--shards", type=int, default=1, help="independent sub-shards (HIP streams) per GPU")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="write the stack of a step in this many lattice ranges, one after the other, into ONE buffer "
+                         "of 1/chunks the size (tq_persp_write_range; a consumer with a small buffer, SURVEY 8d C4)")
     ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
     ap.add_argument("--delivery", default="auto", choices=["auto", "host", "hbm"],
                     help="N>1: where gathered transition blocks end up. host = pinned host replay ring (default for "
@@ -291,6 +294,8 @@ def main():
     ns = n // S
     flush = max(1, args.flush)
     use_events = not args.no_events and not args.graph
+    if args.policy == "nn11" and args.chunks > 1:
+        sys.exit("--policy nn11 reads the whole stack: use --chunks 1")
     if args.graph and (args.policy != "explore" or world > 1 or args.shards != 1):
         sys.exit("--graph supports the single-GPU, single-stream explore policy only")
     if args.graph:
@@ -311,7 +316,10 @@ def main():
     first, _ = G.shard_range(n * world, world, rank)
     # worst case every qubit is a hit (exploration grows the defect density): size each stack for
     # that -- 2.5 GB at d=7 f32, 6.9 GB at d=9 for 65 536 lattices -- out of 288 GB of HBM
-    cap = ns * nq
+    CH = max(1, args.chunks)
+    if ns % CH:
+        sys.exit("--envs / --shards must be divisible by --chunks")
+    cap = (ns // CH) * nq
     row = (ns + 2) & ~1                 # offsets rows of even length: every row starts 16-byte aligned (toricenv.h)
     shards = []
     for k in range(S):
@@ -352,7 +360,11 @@ def main():
                 sh.stream.wait_event(shards[(k - 1) % S].wrote)          # one stack write at a time
             if timed_idx is not None and use_events:
                 sh.ev[timed_idx][0].record(sh.stream)
-            envs.writePerspectives(sh.stack, sh.positions, off)
+            if CH == 1:
+                envs.writePerspectives(sh.stack, sh.positions, off)
+            else:                                                     # the consumer would read the buffer between two chunks
+                for c in range(CH):
+                    envs.writePerspectives(sh.stack, sh.positions, off, first=c * (ns // CH), count=ns // CH)
             if timed_idx is not None and use_events:
                 sh.ev[timed_idx][1].record(sh.stream)
             if S > 1:
@@ -481,7 +493,7 @@ def main():
 
     # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured once at size
     nn_leg = None
-    if world == 1 and args.nn_steps > 0 and args.policy == "explore" and graph is None and S == 1:
+    if world == 1 and args.nn_steps > 0 and args.policy == "explore" and graph is None and S == 1 and CH == 1:
         state["tg"], state["model"] = None, make_model()
         sh0 = shards[0]
         base = W + K
@@ -528,7 +540,7 @@ def main():
                                    (cfg_name, n, d, args.p_error, args.out_dtype, flush, policy_txt),
                        "policy": args.policy, "envs_per_gpu": n, "d": d, "p_error": args.p_error,
                        "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
-                       "streams_per_gpu": S, "hip_graph": bool(args.graph), "parallelism": "env-shard x%d" % world,
+                       "streams_per_gpu": S, "stack_chunks": CH, "hip_graph": bool(args.graph), "parallelism": "env-shard x%d" % world,
                        "steady_state": not args.no_burn_in, "delivery": ("host" if host_delivery else "hbm") if dist_on else None,
                        "gather_roots": roots if dist_on else None,
                        "collective": collective},
@@ -573,7 +585,7 @@ def main():
                                "measured_fill_gbps": fill_gbps, "frac_of_measured_fill": achieved / fill_gbps,
                                "bytes_per_launch": alg, "avg_launch_ms": float(ev_ms.mean()),
                                "median_launch_ms": float(np.median(ev_ms)), "perspectives_per_launch": p_mean,
-                               "launches_per_step": S, "lattices_per_launch": ns}
+                               "launches_per_step": S * CH, "lattices_per_launch": ns // CH}
         if nn_leg is not None:
             res["nn_in_loop"] = nn_leg
         if world == 1 and args.cpu_seconds > 0:

@@ -127,6 +127,12 @@ int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream);
  * lattices that would overflow it are skipped and TQ_E_CAPACITY is latched (tq_check). */
 int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positions,
                    int64_t capacity, int dtype, void* stream);
+/* The same for the lattices [first, first + count) only: `out` / `positions` receive the perspectives
+ * of those lattices, the first one at index 0 (`offsets` is still the whole batch's scan), so a
+ * consumer with a small buffer -- the NN forward of numba/util_actor.py:39-46 works in chunks anyway --
+ * can walk a batch whose whole stack it does not want to hold (d=9: 5.3 GB per 65 536 lattices). */
+int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count, void* out,
+                         int32_t* positions, int64_t capacity, int dtype, void* stream);
 
 /* Same two steps for a batch of syndromes that does not live in a handle (the learner's
  * predictMaxOptimized, util_learner.py:48-111): states = device u8[n,2,d,d]. */

@@ -659,3 +659,34 @@ def test_min_qubit_errors_sampler(T, d, n_err):
     assert ora.episodes.max() >= 3
     gpu.check()
     gpu.close()
+
+
+@pytest.mark.parametrize("d", (3, 7, 9))
+def test_stack_written_in_lattice_ranges(T, d):
+    """tq_persp_write_range: the batch walked in ragged chunks of lattices (chunk borders fall inside
+    128-byte lines of the one-shot stack; empty lattices at the borders), every chunk into the same
+    small buffer: the concatenation is the one-shot stack, positions included, and nothing is written
+    past a chunk's own perspectives."""
+    n = 1000
+    gpu, ora = make_pair(T, d, n, seed=21, numpy_io=False)
+    gpu.resetAll()
+    q = gpu.getQubits().clone()
+    q[100:110] = 0                                            # a run of empty lattices, one chunk border inside it
+    q[399] = 0
+    gpu.setQubits(q)
+    per, pos, cnt = gpu.generatePerspective(dtype=torch.float32)
+    off = gpu._offsets.clone()
+    offh = off.cpu().numpy()
+    nq = 2 * d * d
+    cuts = [0, 1, 105, 400, 401, 777, n]
+    for a, b in zip(cuts, cuts[1:]):
+        k = int(offh[b] - offh[a])
+        buf = torch.full((k * nq + 300,), 7.0, dtype=torch.float32, device=gpu.device)
+        pbuf = torch.full((3 * k + 70,), -5, dtype=torch.int32, device=gpu.device)
+        gpu.writePerspectives(buf[:k * nq].view(k, 2, d, d) if k else buf[:0].view(0, 2, d, d), pbuf, off, first=a, count=b - a)
+        gpu.check()
+        assert torch.equal(buf[:k * nq], per[offh[a]:offh[b]].reshape(-1)) and bool((buf[k * nq:] == 7).all())
+        assert torch.equal(pbuf[:3 * k], pos[offh[a]:offh[b]].reshape(-1)) and bool((pbuf[3 * k:] == -5).all())
+    with pytest.raises(ValueError):
+        gpu.writePerspectives(per, pos, off, first=n - 5, count=6)
+    gpu.close()

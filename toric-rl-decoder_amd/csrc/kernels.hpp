@@ -722,7 +722,7 @@ template <int D, typename OutT>
 __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restrict__ vp, int64_t N,
                                               const int64_t* __restrict__ offsets, OutT* __restrict__ out,
                                               int32_t* __restrict__ pos, int64_t capacity, PerspLds<D>& t,
-                                              int* __restrict__ err, int lane) {
+                                              int* __restrict__ err, int lane, int64_t e_begin, int64_t e_end) {
     using L = Lat<D>;
     using S = PStream<D>;
     using Enc = OutEnc<OutT>;
@@ -737,7 +737,9 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     const int n0 = e0.popc();
     const int n = n0 + e1.popc();
     if (n == 0) return;
-    const int64_t off = offsets[e];
+    // the stack written is that of the lattices [e_begin, e_end): perspective 0 of `out` is the first of e_begin
+    const int64_t off0 = offsets[e_begin];
+    const int64_t off = offsets[e] - off0;
     if (off + n > capacity) { if (lane == 0) atomicOr(err, ERR_CAPACITY); return; }
 
     // ---- tables: rotated planes (ballot), row-rolled planes, column masks, hit list; zeroed stream
@@ -844,7 +846,7 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     const bool s_mixed = F >= lo && F < hi;
     const bool p_mixed = pos != nullptr && PF >= plo && PF < phi;
     if (!s_mixed && !p_mixed) return;
-    const int64_t p_total = offsets[N];
+    const int64_t p_total = offsets[e_end] - off0;
     const int64_t p_cap = p_total < capacity ? p_total : capacity;    // perspectives that may be written
     const int64_t s_limit = p_cap * NQ, p_limit = p_cap * 3;          // nothing is written at or beyond these
     const int64_t s_line_end = F + LE, p_line_end = PF + 32;
@@ -868,7 +870,7 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
         pval = pos_value(t.hits[hidx], k - 3 * hidx);
     }
     int64_t e2 = e + 1, spos = hi, ppos = phi;
-    while (e2 < N && ((s_mixed && spos < s_line_end && spos < s_limit) || (p_mixed && ppos < p_line_end && ppos < p_limit))) {
+    while (e2 < e_end && ((s_mixed && spos < s_line_end && spos < s_limit) || (p_mixed && ppos < p_line_end && ppos < p_limit))) {
         typename L::B v2, p2, f0, f1;
 #pragma unroll
         for (int k = 0; k < W; ++k) { v2.w[k] = vp[(int64_t)k * N + e2]; p2.w[k] = vp[((int64_t)W + k) * N + e2]; }
@@ -920,14 +922,15 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
 template <int D, typename OutT, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_num_sgpr(80))) void k_persp_write(const uint64_t* __restrict__ vp, int64_t N,
                                                          const int64_t* __restrict__ offsets, OutT* __restrict__ out,
-                                                         int32_t* __restrict__ pos, int64_t capacity, int* __restrict__ err) {
+                                                         int32_t* __restrict__ pos, int64_t capacity, int* __restrict__ err,
+                                                         int64_t e_begin, int64_t e_end) {
     constexpr int WAVES = THREADS / 64;
     __shared__ PerspLds<D> tables[WAVES];
     // the wave index is made provably uniform so that the lattice id, its plane words and its
     // offset live in SGPRs (scalar loads) and the hit masks are computed on the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t e = (int64_t)blockIdx.x * WAVES + wave;
-    if (e < N) persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, tables[wave], err, lane);
+    const int64_t e = e_begin + (int64_t)blockIdx.x * WAVES + wave;
+    if (e < e_end) persp_lattice<D, OutT>(e, vp, N, offsets, out, pos, capacity, tables[wave], err, lane, e_begin, e_end);
 }
 
 // generateTransitionParallel on explicit u8 grids: one thread per output byte, the (hit, cell)

@@ -134,7 +134,7 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
 
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
-                         int64_t capacity, int* err, hipStream_t stream) {
+                         int64_t capacity, int* err, hipStream_t stream, int64_t first, int64_t count) {
     // One wave per workgroup: the waves share nothing (no barrier, no common table), and a wave that has
     // finished its lattice is replaced at once instead of waiting for the slowest of four (lattices differ
     // by +-30 % in size): +1 % over 256-thread workgroups, 4 of 4 alternating runs (profiles/r02_wg_size_and_gate.txt).
@@ -143,21 +143,22 @@ int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, 
     // One lattice per wave; the hardware dispatcher balances the variable-size lattices.  Persistent
     // waves (static, or drawing tickets), fixed aligned windows and cooperative workgroups were all
     // built or prototyped and are slower or equal in the real kernel (git history).
-    const int64_t blocks = (n + WAVES - 1) / WAVES;
+    const int64_t blocks = (count + WAVES - 1) / WAVES;
     hipLaunchKernelGGL((tq::k_persp_write<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
-                       offsets, (OutT*)out, pos, capacity, err);
+                       offsets, (OutT*)out, pos, capacity, err, first, first + count);
     KCHECK();
     return TQ_OK;
 }
 
 template <int D>
 int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
-                       int64_t capacity, int dtype, int* err, hipStream_t stream) {
+                       int64_t capacity, int dtype, int* err, hipStream_t stream, int64_t first, int64_t count) {
+    if (count == 0) return TQ_OK;
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream);
-        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -437,18 +438,25 @@ int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream_) 
     return TQ_OK;
 }
 
-int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positions, int64_t capacity,
-                   int dtype, void* stream_) {
+int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count, void* out, int32_t* positions,
+                         int64_t capacity, int dtype, void* stream_) {
     HANDLE(h);
     if (!offsets || !out) return fail(TQ_E_INVALID, "offsets / out is NULL");
     if (capacity < 0) return fail(TQ_E_INVALID, "negative capacity");
+    if (first < 0 || count < 0 || (int64_t)first + count > h->n) return fail(TQ_E_INVALID, "lattice range outside [0, n_envs)");
     REQUIRE_ALIGNED16(out, "out");
     REQUIRE_ALIGNED16(positions, "positions");
     const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream, first, count)) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;
+}
+
+int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positions, int64_t capacity,
+                   int dtype, void* stream_) {
+    if (!h) return fail(TQ_E_INVALID, "NULL handle");
+    return tq_persp_write_range(h, offsets, 0, h->n, out, positions, capacity, dtype, stream_);
 }
 
 // ---- stateless variants (states outside a handle) -------------------------------------------
@@ -532,7 +540,7 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, err, stream)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, err, stream, 0, n)) return rc
     DISPATCH_D(d, CALL)
 #undef CALL
     return TQ_OK;

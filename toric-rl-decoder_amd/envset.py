@@ -358,9 +358,11 @@ class EnvSet:
         self._call(self._L.tq_persp_count, _ptr(self._counts), _ptr(self._offsets))
         return self._counts, self._offsets
 
-    def writePerspectives(self, out, positions=None, offsets=None):
+    def writePerspectives(self, out, positions=None, offsets=None, first=0, count=None):
         """Write the stack for ``offsets`` (default: the last perspectiveCounts) into the
-        caller's tensor ``out`` (capacity = out.shape[0] perspectives).  No synchronisation."""
+        caller's tensor ``out`` (capacity = out.shape[0] perspectives).  No synchronisation.
+        ``first`` / ``count``: only the lattices [first, first+count), their first perspective at
+        out[0] -- for consumers that walk the batch in chunks."""
         if out.dtype not in _DTYPES or not out.is_contiguous():
             raise ValueError("out must be a contiguous float32/float16/bfloat16/uint8 tensor")
         nq = 2 * self.size * self.size
@@ -368,7 +370,12 @@ class EnvSet:
         if positions is not None and (positions.dtype != torch.int32 or positions.numel() < 3 * cap):
             raise ValueError("positions must be int32 with at least 3*capacity elements")
         off = self._offsets if offsets is None else offsets
-        self._call(self._L.tq_persp_write, _ptr(off), _ptr(out), _ptr(positions), cap, _DTYPES[out.dtype])
+        if first == 0 and count is None:
+            self._call(self._L.tq_persp_write, _ptr(off), _ptr(out), _ptr(positions), cap, _DTYPES[out.dtype])
+        else:
+            count = self.no_envs - int(first) if count is None else int(count)
+            self._call(self._L.tq_persp_write_range, _ptr(off), int(first), count, _ptr(out), _ptr(positions), cap,
+                       _DTYPES[out.dtype])
         self._positions = positions
 
     def generatePerspective(self, states=None, dtype=torch.float32):

@@ -84,8 +84,22 @@ __device__ __forceinline__ int kth_hit(const typename Lat<D>::B& e0, const typen
             found = found || here;
         }
     }
-    for (int t = 0; t < k; ++t) word &= word - 1;      // drop the k lowest set bits
-    return base + (int)__ffsll((long long)word) - 1;
+    // position of the k-th set bit of `word` (k < popc(word)): binary search on popcounts, six steps,
+    // no data-dependent loop (a wave pays for its slowest lane)
+    uint32_t w32 = (uint32_t)word;
+    int posn = 0;
+    {
+        const int c = __popc(w32);
+        const bool up = k >= c;
+        k = up ? k - c : k; posn = up ? 32 : 0; w32 = up ? (uint32_t)(word >> 32) : w32;
+    }
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        const int c = __popc(w32 & ((1u << s) - 1u));
+        const bool up = k >= c;
+        k = up ? k - c : k; posn += up ? s : 0; w32 = up ? (w32 >> s) : w32;
+    }
+    return base + posn;
 }
 
 struct PerrSchedule {
@@ -213,18 +227,38 @@ __host__ __device__ inline int64_t block_bytes(int W, int64_t cap) {
     return 4 * 8 * (int64_t)W * cap + 3 * align8(4 * cap) + align8(cap);
 }
 
+// The four checks of the acted qubit in ITS OWN centred frame -- v[gs,gs], v[gs+1,gs], p[gs,gs], p[gs,gs-1], for
+// either layer (centred-frame property) -- so the perspective of the post-step syndrome is the
+// perspective of the pre-step syndrome with these bits flipped: Z component -> the two vertices, X component
+// -> the two plaquettes.  (perspective() is linear over GF(2).)
+template <int D>
+__device__ __forceinline__ void centred_flip(int op, typename Lat<D>::B& dv, typename Lat<D>::B& dp) {
+    using L = Lat<D>;
+    constexpr int GS = L::GS;
+    dv = L::B::zero(); dp = L::B::zero();
+    const int fx = (op == 1) | (op == 2), fz = (op >> 1) & 1;
+    dv.flip(GS * D + GS, fz); dv.flip((GS + 1) * D + GS, fz);
+    dp.flip(GS * D + GS, fx); dp.flip(GS * D + GS - 1, fx);
+}
+
 template <int D>
 __device__ __forceinline__ void write_transition(const BlockView& b, int64_t slot, const typename Lat<D>::B& v0,
                                                  const typename Lat<D>::B& p0, const typename Lat<D>::B& v1,
                                                  const typename Lat<D>::B& p1, int layer, int row, int col, int op,
-                                                 float reward, int terminal) {
+                                                 float reward, int terminal, bool stepped = false) {
     using L = Lat<D>;
     constexpr int W = L::W;
     typename L::B a, c;
     L::perspective(v0, p0, layer, row, col, a, c);
 #pragma unroll
     for (int k = 0; k < W; ++k) { b.pv[(int64_t)k * b.cap + slot] = a.w[k]; b.pp[(int64_t)k * b.cap + slot] = c.w[k]; }
-    L::perspective(v1, p1, layer, row, col, a, c);
+    if (stepped) {                                            // (v1,p1) = (v0,p0) after `op` on this very qubit
+        typename L::B dv, dp;
+        centred_flip<D>(op, dv, dp);
+        a = a ^ dv; c = c ^ dp;
+    } else {
+        L::perspective(v1, p1, layer, row, col, a, c);
+    }
 #pragma unroll
     for (int k = 0; k < W; ++k) { b.nv[(int64_t)k * b.cap + slot] = a.w[k]; b.np[(int64_t)k * b.cap + slot] = c.w[k]; }
     // action rewritten to the centred frame (util_actor.py:256,261)
@@ -350,7 +384,7 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
     if (rewards && valid) rewards[e] = reward;
     if (terminals && valid) terminals[e] = (uint8_t)terminal;
     if (has_block && valid) {                                // every slot is written, every step: no stale records
-        if (ok) write_transition<D>(blk, slot_base + e, v0, p0, s.v, s.p, layer, row, col, op, reward, terminal);
+        if (ok) write_transition<D>(blk, slot_base + e, v0, p0, s.v, s.p, layer, row, col, op, reward, terminal, true);
         else write_empty_slot<D>(blk, slot_base + e);
     }
     // reset policy of the caller (Actor_mp.py:171-183).  Few lanes of a wave reset in a given step, so

@@ -11,10 +11,11 @@
 //     In bit-plane form a whole-lattice syndrome is ~20 shifts/xors, so there is nothing to
 //     share between lanes; 65 536 lattices = 1 024 wavefronts.  (Exception: the few resets inside
 //     the fused step are served by the whole wave, one qubit per lane, planes built by __ballot.)
-//   * perspective stack write (the HBM-bound kernel): ONE WAVEFRONT PER LATTICE.  The hit list,
-//     the syndrome cells and the (hit, cell) -> source-cell table sit in LDS; periodic shifts and
-//     the layer-1 rotation are LDS index lookups; every lane stores 16 B, so one wave
-//     instruction writes 1 KiB of the contiguous (n_hits, 2, d, d) segment of its lattice.
+//   * perspective stack write (the HBM-bound kernel): ONE WAVEFRONT PER LATTICE.  The lattice's
+//     perspectives are first built as ONE bit string in LDS with bit-plane operations (periodic
+//     shifts = plane rolls, the layer-1 rotation = the same rolls on the once-rotated planes; one
+//     lane per hit), then expanded: every lane stores 16 B, so one wave instruction writes 1 KiB of
+//     the contiguous (n_hits, 2, d, d) segment of its lattice.  No lookup table, no vector load.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>

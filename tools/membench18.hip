@@ -136,7 +136,23 @@ int main() {
     CK(hipMemcpy(d_off, offb.data(), (nseg + 1) * 8, hipMemcpyHostToDevice));
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf("total %.3f GB in %ld segments\n", total * 1e-9, (long)nseg);
-    for (int rep = 0; rep < 2; ++rep) {
+    // burst (one launch between two events, host sync in between) vs sustained (200 launches back to back)
+    auto sustained = [&](const char* name, auto launch) {
+        for (int i = 0; i < 5; ++i) launch();
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < 200; ++i) launch();
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("%-52s %.3f ms  %5.0f GB/s   (200 launches back to back)\n", name, ms / 200, g_bytes / (ms / 200) * 1e-6);
+        fflush(stdout);
+    };
+    sustained("SUSTAINED hipMemsetAsync", [&] { (void)hipMemsetAsync(out, 0, total, 0); });
+    sustained("SUSTAINED fill 32 KB windows, G=2048", [&] { hipLaunchKernelGGL(fill<32768>, dim3(2048), dim3(256), 0, 0, out, total / 32768); });
+    sustained("SUSTAINED winw 32 KB windows (wave), G=2048, S=0", [&] { hipLaunchKernelGGL(winw<32768>, dim3(2048), dim3(256), 0, 0, out, total / 32768, 0); });
+    sustained("SUSTAINED segs: one wave per segment, S=0", [&] { hipLaunchKernelGGL(segs, dim3(nseg / 4), dim3(256), 0, 0, out, d_off, nseg, 0); });
+    sustained("SUSTAINED segs: one wave per segment, S=300", [&] { hipLaunchKernelGGL(segs, dim3(nseg / 4), dim3(256), 0, 0, out, d_off, nseg, 300); });
+    sustained("SUSTAINED segs: one wave per segment, S=1000", [&] { hipLaunchKernelGGL(segs, dim3(nseg / 4), dim3(256), 0, 0, out, d_off, nseg, 1000); });
+    for (int rep = 0; rep < 1; ++rep) {
         timeit("hipMemsetAsync", [&] { (void)hipMemsetAsync(out, 0, total, 0); });
         for (int S : {0, 300, 1000}) {
             char name[96];

@@ -775,6 +775,17 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     // the stack written is that of the lattices [e_begin, e_end): perspective 0 of `out` is the first of e_begin
     const int64_t off0 = offsets[e_begin];
     const int64_t off = offsets[e] - off0;
+    // What the mixed last line needs from outside this lattice -- the planes of the lattice behind it and the
+    // length of the stack -- is fetched here, in the same scalar-load round trip as the lattice's own data,
+    // not when the wave is about to finish.
+    const int64_t p_total = offsets[e_end] - off0;
+    const bool has_next = e + 1 < e_end;
+    typename L::B v_next, p_next;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        v_next.w[k] = has_next ? vp[(int64_t)k * N + e + 1] : 0ull;
+        p_next.w[k] = has_next ? vp[((int64_t)W + k) * N + e + 1] : 0ull;
+    }
     if (off + n > capacity) { if (lane == 0) atomicOr(err, ERR_CAPACITY); return; }
 
     // ---- tables: rotated planes (ballot), row-rolled planes, column masks, hit list; zeroed stream
@@ -855,33 +866,15 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     const int64_t A = (lo + LE - 1) / LE * LE;               // first line start >= lo
     const int64_t F = hi / LE * LE;                          // last line start <= hi
 
-    // ---- whole lines inside the segment: [A, F)
-    if (F > A) {
-        // Lane `lane` writes 16-byte groups lane, lane+64, ... of [A, F); group g holds the stream bits
-        // rel0 + g*VEC ... : the dword index advances by 2*VEC per iteration, the bit phase never changes.
-        const int n_groups = (int)((F - A) / VEC);
-        char* __restrict__ seg = reinterpret_cast<char*>(out + A);            // wave-uniform, 128-byte aligned
-        const uint32_t rel0 = (uint32_t)(A - lo) + (uint32_t)lane * VEC;
-        const uint32_t ph = rel0 & 31u;
-        const uint32_t* __restrict__ bp = t.bits + (rel0 >> 5);
-        uint32_t w0 = 0, w1 = 0;
-        if (lane < n_groups) { w0 = bp[0]; w1 = bp[1]; }
-        for (int gi = lane; gi < n_groups; gi += 64) {
-            const uint32_t wb = (uint32_t)(((((uint64_t)w1) << 32) | w0) >> ph);
-            bp += 2 * VEC;
-            if (gi + 64 < n_groups) { w0 = bp[0]; w1 = bp[1]; }              // next window is in flight while this one is stored
-            *reinterpret_cast<u32x4*>(seg + (uint32_t)gi * 16u) = expand_bits<OutT>(wb);
-        }
-    }
-
     // ---- mixed last lines: the stack line [F, F+LE) on lanes 0..31 and the positions line
     // [PF, PF+32) on lanes 32..63, each present when the lattice's range ends inside a line that
     // starts in it.  Their trailing elements belong to the lattices that follow: one wave-uniform
     // walk over those lattices serves both.
+    // This is done BEFORE the main loop so that the wave's last instructions are its stores: it retires as soon
+    // as they are issued and its slot goes to the next lattice.
     const bool s_mixed = F >= lo && F < hi;
     const bool p_mixed = pos != nullptr && PF >= plo && PF < phi;
-    if (!s_mixed && !p_mixed) return;
-    const int64_t p_total = offsets[e_end] - off0;
+    if (s_mixed || p_mixed) {
     const int64_t p_cap = p_total < capacity ? p_total : capacity;    // perspectives that may be written
     const int64_t s_limit = p_cap * NQ, p_limit = p_cap * 3;          // nothing is written at or beyond these
     const int64_t s_line_end = F + LE, p_line_end = PF + 32;
@@ -906,9 +899,11 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     }
     int64_t e2 = e + 1, spos = hi, ppos = phi;
     while (e2 < e_end && ((s_mixed && spos < s_line_end && spos < s_limit) || (p_mixed && ppos < p_line_end && ppos < p_limit))) {
-        typename L::B v2, p2, f0, f1;
+        typename L::B v2 = v_next, p2 = p_next, f0, f1;
+        if (e2 != e + 1) {                                   // beyond the prefetched neighbour (tiny or empty lattices only)
 #pragma unroll
-        for (int k = 0; k < W; ++k) { v2.w[k] = vp[(int64_t)k * N + e2]; p2.w[k] = vp[((int64_t)W + k) * N + e2]; }
+            for (int k = 0; k < W; ++k) { v2.w[k] = vp[(int64_t)k * N + e2]; p2.w[k] = vp[((int64_t)W + k) * N + e2]; }
+        }
         L::hit_masks(v2, p2, f0, f1);
         const int n2 = f0.popc() + f1.popc();
         const int64_t send = spos + (int64_t)n2 * NQ, pend = ppos + 3 * n2;
@@ -949,6 +944,26 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
         }
     }
     if (p_lane && y < p_limit) pos[y] = pval;
+    }
+
+    // ---- whole lines inside the segment: [A, F)
+    if (F > A) {
+        // Lane `lane` writes 16-byte groups lane, lane+64, ... of [A, F); group g holds the stream bits
+        // rel0 + g*VEC ... : the dword index advances by 2*VEC per iteration, the bit phase never changes.
+        const int n_groups = (int)((F - A) / VEC);
+        char* __restrict__ seg = reinterpret_cast<char*>(out + A);            // wave-uniform, 128-byte aligned
+        const uint32_t rel0 = (uint32_t)(A - lo) + (uint32_t)lane * VEC;
+        const uint32_t ph = rel0 & 31u;
+        const uint32_t* __restrict__ bp = t.bits + (rel0 >> 5);
+        uint32_t w0 = 0, w1 = 0;
+        if (lane < n_groups) { w0 = bp[0]; w1 = bp[1]; }
+        for (int gi = lane; gi < n_groups; gi += 64) {
+            const uint32_t wb = (uint32_t)(((((uint64_t)w1) << 32) | w0) >> ph);
+            bp += 2 * VEC;
+            if (gi + 64 < n_groups) { w0 = bp[0]; w1 = bp[1]; }              // next window is in flight while this one is stored
+            *reinterpret_cast<u32x4*>(seg + (uint32_t)gi * 16u) = expand_bits<OutT>(wb);
+        }
+    }
 }
 
 // SGPRs capped at 80: up to 80 a CU admits 8 of these workgroups (32 waves); the d >= 9 instantiations would

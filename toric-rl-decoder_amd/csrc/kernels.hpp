@@ -707,7 +707,7 @@ struct PerspLds {
     __attribute__((aligned(16))) uint32_t bits[BITS_DW];       // bit pidx*NQ + cell = element `cell` of perspective pidx
     uint64_t rr[4][D][Lat<D>::W];                              // V, P, rot V, rot P rolled by every row amount
     uint64_t low[D][Lat<D>::W];                                // lowcols(k): destination columns [0,k) of a column roll
-    uint8_t hits[NQP];                                         // k-th hit -> flat qubit index
+    uint32_t hpos[NQP];                                        // k-th hit -> its position, packed layer | row << 8 | col << 16
 };
 
 // `VEC` stream bits -> the four dwords of one 16-byte lane store
@@ -814,7 +814,10 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     }
     for (int c = lane; c < NQ; c += 64) {
         const int l = c >= DD, bit = c - l * DD;
-        if (l ? e1.get(bit) : e0.get(bit)) t.hits[l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint8_t)c;
+        if (l ? e1.get(bit) : e0.get(bit)) {
+            const int row = bit / D, col = bit - row * D;
+            t.hpos[l ? n0 + e1.rank(bit) : e0.rank(bit)] = (uint32_t)l | ((uint32_t)row << 8) | ((uint32_t)col << 16);
+        }
     }
     {
         const int nd4 = ((n * NQ + 31) / 32 + 2 + 3) / 4;     // <= BITS_DW / 4
@@ -825,8 +828,8 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
 
     // ---- one lane per hit: its perspective as two bit-planes, OR-ed into the stream
     for (int k = lane; k < n; k += 64) {
-        const int h = t.hits[k];
-        const int layer = h >= DD, rem = h - layer * DD, i = rem / D, j = rem - i * D;
+        const uint32_t hp = t.hpos[k];
+        const int layer = (int)(hp & 255u), i = (int)((hp >> 8) & 255u), j = (int)(hp >> 16);
         int rs, cs;
         S::hit_shifts(layer, i, j, rs, cs);
         typename L::B a, c, low;
@@ -842,10 +845,6 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     // mixed last line further down together with the stack's.
     const int64_t plo = off * 3, phi = plo + 3 * n;
     const int64_t PA = (plo + 31) / 32 * 32, PF = phi / 32 * 32;
-    auto pos_value = [&](int h, int comp) -> int {           // h = flat qubit index of the hit
-        const int l = h >= DD, rem = h - l * DD, row = rem / D, col = rem - row * D;
-        return comp == 0 ? l : (comp == 1 ? row : col);
-    };
     if (pos && PF > PA) {
         const int n_g = (int)((PF - PA) / 4);
         int4* __restrict__ pseg = reinterpret_cast<int4*>(pos + PA);
@@ -855,7 +854,7 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + j, hidx = k / 3;
-                o[j] = pos_value(t.hits[hidx], k - 3 * hidx);
+                o[j] = (int)((t.hpos[hidx] >> (8 * (k - 3 * hidx))) & 255u);
             }
             pseg[g] = make_int4(o[0], o[1], o[2], o[3]);
         }
@@ -875,75 +874,82 @@ __device__ __forceinline__ void persp_lattice(int64_t e, const uint64_t* __restr
     const bool s_mixed = F >= lo && F < hi;
     const bool p_mixed = pos != nullptr && PF >= plo && PF < phi;
     if (s_mixed || p_mixed) {
-    const int64_t p_cap = p_total < capacity ? p_total : capacity;    // perspectives that may be written
-    const int64_t s_limit = p_cap * NQ, p_limit = p_cap * 3;          // nothing is written at or beyond these
-    const int64_t s_line_end = F + LE, p_line_end = PF + 32;
-    const bool s_lane = s_mixed && lane < 32, p_lane = p_mixed && lane >= 32;
-    const int64_t x0 = F + lane * EPW;                       // stack: this lane's dword = elements x0 .. x0+EPW-1
-    const int64_t y = PF + (lane - 32);                      // positions: this lane's dword
-    uint32_t word = 0;
-    int pval = 0;
-    if (s_lane) {
-#pragma unroll
-        for (int j = 0; j < EPW; ++j) {                      // own elements
-            const int64_t x = x0 + j;
-            if (x < hi) {
-                const uint32_t b = S::window(t.bits, (uint32_t)(x - lo)) & 1u;
-                word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
-            }
-        }
-    }
-    if (p_lane && y < phi) {
-        const int k = (int)(y - plo), hidx = k / 3;
-        pval = pos_value(t.hits[hidx], k - 3 * hidx);
-    }
-    int64_t e2 = e + 1, spos = hi, ppos = phi;
-    while (e2 < e_end && ((s_mixed && spos < s_line_end && spos < s_limit) || (p_mixed && ppos < p_line_end && ppos < p_limit))) {
-        typename L::B v2 = v_next, p2 = p_next, f0, f1;
-        if (e2 != e + 1) {                                   // beyond the prefetched neighbour (tiny or empty lattices only)
-#pragma unroll
-            for (int k = 0; k < W; ++k) { v2.w[k] = vp[(int64_t)k * N + e2]; p2.w[k] = vp[((int64_t)W + k) * N + e2]; }
-        }
-        L::hit_masks(v2, p2, f0, f1);
-        const int n2 = f0.popc() + f1.popc();
-        const int64_t send = spos + (int64_t)n2 * NQ, pend = ppos + 3 * n2;
+        // all positions below are relative to the start of the mixed line (stack: elements, positions: dwords)
+        const int64_t p_cap = p_total < capacity ? p_total : capacity;   // perspectives that may be written
+        const int64_t s_room = p_cap * NQ - F, p_room = p_cap * 3 - PF;  // what lies inside the stack from the line start on
+        const int s_lim = s_room < LE ? (int)s_room : LE, p_lim = p_room < 32 ? (int)p_room : 32;
+        const int s_own = s_mixed ? (int)(hi - F) : LE;                  // this lattice's part of the line
+        const int p_own = p_mixed ? (int)(phi - PF) : 32;
+        const bool s_lane = s_mixed && lane < 32, p_lane = p_mixed && lane >= 32;
+        const int xr0 = lane * EPW;                          // stack: this lane's dword = elements xr0 .. xr0+EPW-1 of the line
+        const int yr = lane - 32;                            // positions: this lane's dword of the line
+        uint32_t word = 0;
+        int pval = 0;
         if (s_lane) {
 #pragma unroll
-            for (int j = 0; j < EPW; ++j) {
-                const int64_t x = x0 + j;
-                if (x >= spos && x < send) {
-                    const int rel = (int)(x - spos);         // < LE
-                    const int pidx = rel / NQ, cell = rel - pidx * NQ;
-                    const int h = kth_hit<D>(f0, f1, pidx);
-                    const int hl = h >= DD, hrem = h - hl * DD, hi_ = hrem / D, hj = hrem - hi_ * D;
-                    const int cc = cell >= DD, crem = cell - cc * DD, cr = crem / D, cs_ = crem - cr * D;
-                    const int src = L::persp_src(hl, hi_, hj, cc, cr, cs_);
-                    const uint32_t b = (uint32_t)(src >= DD ? p2.get(src - DD) : v2.get(src));
+            for (int j = 0; j < EPW; ++j) {                  // own elements
+                if (xr0 + j < s_own) {
+                    const uint32_t b = S::window(t.bits, (uint32_t)(F - lo) + (uint32_t)(xr0 + j)) & 1u;
                     word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
                 }
             }
         }
-        if (p_lane && y >= ppos && y < pend) {
-            const int k = (int)(y - ppos), hidx = k / 3;      // < 32
-            pval = pos_value(kth_hit<D>(f0, f1, hidx), k - 3 * hidx);
+        if (p_lane && yr < p_own) {
+            const int k = (int)(PF - plo) + yr, hidx = k / 3;
+            pval = (int)((t.hpos[hidx] >> (8 * (k - 3 * hidx))) & 255u);
         }
-        spos = send;
-        ppos = pend;
-        ++e2;
-    }
-    if (s_lane) {
-        if (x0 + EPW <= s_limit) {
-            reinterpret_cast<uint32_t*>(out)[x0 / EPW] = word;
-        } else {
+        int64_t e2 = e + 1;
+        int spos = s_own, ppos = p_own;
+        while (e2 < e_end && ((s_mixed && spos < s_lim) || (p_mixed && ppos < p_lim))) {
+            typename L::B v2 = v_next, p2 = p_next, f0, f1;
+            if (e2 != e + 1) {                               // beyond the prefetched neighbour (tiny or empty lattices only)
 #pragma unroll
-            for (int j = 0; j < EPW; ++j)                    // the stack ends inside this dword
-                if (x0 + j < s_limit) {
-                    if (Enc::BITS == 16) reinterpret_cast<uint16_t*>(out)[x0 + j] = (uint16_t)(word >> (16 * j));
-                    else if (Enc::BITS == 8) reinterpret_cast<uint8_t*>(out)[x0 + j] = (uint8_t)(word >> (8 * j));
+                for (int k = 0; k < W; ++k) { v2.w[k] = vp[(int64_t)k * N + e2]; p2.w[k] = vp[((int64_t)W + k) * N + e2]; }
+            }
+            L::hit_masks(v2, p2, f0, f1);
+            const int n2 = f0.popc() + f1.popc();
+            const int send = spos + n2 * NQ, pend = ppos + 3 * n2;
+#pragma unroll
+            for (int j = 0; j < EPW; ++j) {
+                // one k-th-hit search serves both halves of the wave: stack lanes ask for the hit of their
+                // element's perspective, position lanes (first pass only) for the hit of their dword
+                const int xr = xr0 + j;
+                const bool s_act = s_lane && xr >= spos && xr < send;
+                const bool p_act = j == 0 && p_lane && yr >= ppos && yr < pend;
+                if (s_act || p_act) {
+                    const int rel = s_act ? xr - spos : yr - ppos;                // < LE / < 32
+                    const int kq = s_act ? rel / NQ : rel / 3;
+                    const int h = kth_hit<D>(f0, f1, kq);
+                    const int hl = h >= DD, hrem = h - hl * DD, hi_ = hrem / D, hj = hrem - hi_ * D;
+                    if (s_act) {
+                        const int cell = rel - kq * NQ;
+                        const int cc = cell >= DD, crem = cell - cc * DD, cr = crem / D, cs_ = crem - cr * D;
+                        const int src = L::persp_src(hl, hi_, hj, cc, cr, cs_);
+                        const uint32_t b = (uint32_t)(src >= DD ? p2.get(src - DD) : v2.get(src));
+                        word |= ((0u - b) & Enc::ONE) << (j * Enc::BITS);
+                    } else {
+                        const int comp = rel - 3 * kq;
+                        pval = comp == 0 ? hl : (comp == 1 ? hi_ : hj);
+                    }
                 }
+            }
+            spos = send;
+            ppos = pend;
+            ++e2;
         }
-    }
-    if (p_lane && y < p_limit) pos[y] = pval;
+        if (s_lane) {
+            if (xr0 + EPW <= s_lim) {
+                reinterpret_cast<uint32_t*>(out)[(F + xr0) / EPW] = word;
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPW; ++j)                // the stack ends inside this dword
+                    if (xr0 + j < s_lim) {
+                        if (Enc::BITS == 16) reinterpret_cast<uint16_t*>(out)[F + xr0 + j] = (uint16_t)(word >> (16 * j));
+                        else if (Enc::BITS == 8) reinterpret_cast<uint8_t*>(out)[F + xr0 + j] = (uint8_t)(word >> (8 * j));
+                    }
+            }
+        }
+        if (p_lane && yr < p_lim) pos[PF + yr] = pval;
     }
 
     // ---- whole lines inside the segment: [A, F)

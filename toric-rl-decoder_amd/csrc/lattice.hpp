@@ -209,11 +209,15 @@ struct Lat {
     //   layer 1: P1[1,r,s] = state[1,(s+i-gs)%d,(d-1-r+j-gs)%d]
     //            P1[0,r,s] = state[0,(s+i-gs)%d,((d-r)%d+j-gs)%d]
     TQ_HD static int persp_src(int layer, int i, int j, int c, int r, int s) {
-        const int a = (i - GS + D) % D, b = (j - GS + D) % D;
+        // every "% D" below has an argument in [0, 2D): a conditional subtraction (no division on the device)
+        int a = i - GS + D, b = j - GS + D;
+        a = a >= D ? a - D : a; b = b >= D ? b - D : b;
         int row, col;
         if (layer == 0) { row = r; col = s; }
-        else { row = s; col = c ? (D - 1 - r) : (D - r) % D; }
-        return c * DD + ((row + a) % D) * D + (col + b) % D;
+        else { row = s; col = c ? (D - 1 - r) : (r ? D - r : 0); }
+        row += a; col += b;
+        row = row >= D ? row - D : row; col = col >= D ? col - D : col;
+        return c * DD + row * D + col;
     }
 
     // The perspective of (v,p) centred on qubit (layer,i,j), as bit-planes

@@ -277,6 +277,8 @@ def main():
     dist_on = world > 1 or os.environ.get("TORIC_FORCE_DIST") == "1"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))       # a world of one rank rendezvouses with itself
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:

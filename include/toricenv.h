@@ -77,7 +77,8 @@ int tq_destroy(tq_env* h);
 
 /* env config: default p_error in (0,1] (gym config "p_error"), terminal reward (default 100,
  * evaluation.py:175), max_actions_per_episode (default 75, Distributed_mp.py:44; used only by
- * tq_actor_step's auto-reset). */
+ * tq_actor_step's auto-reset).  p_error = 0 is rejected (a reset could never produce a defect) unless the
+ * fixed-n sampler was selected first with tq_set_min_qubit_errors(n > 0), which does not use p_error. */
 int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int max_steps_per_episode);
 /* gym config "min_qubit_errors": 0 (default, every config of the reference tree) = depolarizing
  * sampler at p_error; n > 0 = every reset places exactly n errors on uniformly chosen distinct
@@ -207,7 +208,10 @@ int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, i
  *   priority = | reward + discount * max_a Q[t+1][e][a] - Q[t][e][op-1] |   (f64 arithmetic, stored f32)
  * q_values = device f32[n_steps+1][n_envs][3]: the q_values selectActionBatch returned at each of the
  * n_steps steps plus the step after (local_buffer_Q and its np.roll(-1), Actor_mp.py:146-150);
- * NULL = all zeros (pure exploration).  Empty slots get priority 0. */
+ * NULL = all zeros (pure exploration).  Empty slots get priority 0.
+ * Width: the reference's priorities are float64 (util_actor.py:287); the wire field is float32 -- the one
+ * field of the record that is narrower than upstream.  The arithmetic is f64 and rounded once, so the
+ * stored value is exactly float32(reference priority); a sum tree that needs f64 widens it on ingest. */
 int tq_block_priorities(int d, void* block, int64_t cap, int n_envs, int n_steps,
                         const float* q_values, double discount, void* stream);
 

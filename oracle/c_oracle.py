@@ -110,6 +110,17 @@ class CEnvBatch:
         self.L.tor_persp_write(n, d, s, offsets, u8, f32, pos.ctypes.data)
         return out, pos, counts, offsets
 
+    def positions(self, states=None):
+        """(positions (P,3), counts, offsets) without materialising the stack (full-size shards)."""
+        s = self.states if states is None else np.ascontiguousarray(states, np.uint8)
+        n, d = s.shape[0], self.size
+        counts = np.empty(n, np.int32)
+        offsets = np.empty(n + 1, np.int64)
+        self.L.tor_persp_count(n, d, s, counts, offsets)
+        pos = np.empty((int(offsets[-1]), 3), np.int32)
+        self.L.tor_persp_write(n, d, s, offsets, None, None, pos.ctypes.data)
+        return pos, counts, offsets
+
     def transition(self, actions, states, next_states):
         n, d = self.no_envs, self.size
         a = np.ascontiguousarray(actions, np.int32).reshape(n, 4)

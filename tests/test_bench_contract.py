@@ -71,8 +71,8 @@ def test_bench_rccl_path_keeps_stdout_to_one_line():
     """The collective path over RCCL (a world of one rank on this box, TORIC_FORCE_DIST=1) with delivery to
     the pinned host ring: RCCL prints its version banner on stdout when the communicator comes up -- the
     bench must still print exactly one line there -- and the line carries the HBM-ring rate beside it."""
-    env = dict(os.environ, TORIC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    env = dict(os.environ, TORIC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):   # no port given: bench.py picks a free one
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--envs", "8192",
                         "--cpu-seconds", "0", "--nn-steps", "0"], capture_output=True, text=True, timeout=600, env=env)

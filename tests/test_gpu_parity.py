@@ -690,3 +690,53 @@ def test_stack_written_in_lattice_ranges(T, d):
     with pytest.raises(ValueError):
         gpu.writePerspectives(per, pos, off, first=n - 5, count=6)
     gpu.close()
+
+
+def test_fresh_handle_is_usable_at_once_on_a_non_blocking_stream(T):
+    """tq_create allocates AND synchronises: a handle created while another one is busy can be reset at once on a
+    non-blocking stream (PyTorch side streams are) -- its counters must already be zero, or the Philox counters of
+    the first episode would be wrong."""
+    d, n = 7, 65536
+    busy, _ = make_pair(T, d, n, seed=8, numpy_io=False)
+    busy.resetAll()
+    side = torch.cuda.Stream()                                # hipStreamNonBlocking
+    for rep in range(4):
+        for _ in range(6):
+            busy.actorStep(None, want_actions=False)          # keep the null-stream side of the device busy
+        with torch.cuda.stream(side):
+            fresh, ora = make_pair(T, d, n, seed=100 + rep, first=5 * n, numpy_io=False)
+            fresh.resetAll()
+            st = fresh.getStates().clone()
+            ep, steps = fresh.getCounters()
+            ep, steps = ep.clone(), steps.clone()
+        side.synchronize()
+        assert np.array_equal(st.cpu().numpy(), ora.resetAll())
+        assert bool((ep == 1).all()) and bool((steps == 0).all())
+        fresh.close()
+    busy.close()
+
+
+def test_fixed_n_sampler_accepts_p_error_zero(T):
+    """{min_qubit_errors: n, p_error: 0} is a valid config (the small-p regime of results/small_p_error_test.py):
+    the fixed-n sampler does not use p_error; with the depolarizing sampler p_error = 0 stays rejected."""
+    d, n = 5, 200
+    env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": 3, "p_error": 0.0})
+    gpu = T.EnvSet(env, n, seed=4, numpy_io=False)
+    ora = O.OracleEnvSet(d, n, 0.0, seed=4, min_qubit_errors=3)
+    gpu.resetAll()
+    ora.resetAll()
+    assert np.array_equal(gpu.getQubits().cpu().numpy(), ora.qubits)
+    gpu.check()
+    L = T.load()
+    assert L.tq_set_min_qubit_errors(gpu._h, 0) == -1 and b"depolarizing" in L.tq_last_error()   # would leave p = 0 in charge
+    gpu.close()
+    with pytest.raises(ValueError):
+        T.EnvSet(T.make("toric-code-v0", {"size": d, "min_qubit_errors": 0, "p_error": 0.0}), n)
+    # createSyndromOpt re-uses one scratch lattice
+    e1 = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+    qm = np.zeros((2, d, d), np.int64)
+    qm[1, 3, 1] = 2
+    a = e1.createSyndromOpt(qm)
+    scratch = e1._scratch
+    b = e1.createSyndromOpt(np.zeros((2, d, d), np.int64))
+    assert e1._scratch is scratch and np.array_equal(a, O.syndrome(qm)) and not b.any()

@@ -369,8 +369,12 @@ def test_transition_gather_rccl_single_rank_with_host_drain(T):
     import os
     import torch.distributed as dist
     from toric_rl_decoder_amd import gather, wire
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29571")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])       # a free port, not a pinned one
+    sock.close()
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
@@ -401,6 +405,15 @@ def test_transition_gather_rccl_single_rank_with_host_drain(T):
         records, prio = wire.to_records(rec, d)
         assert np.array_equal(prio.view(np.uint32), want.view(np.uint32)) and np.array_equal(prio, np.abs(rec["reward"]))
         assert records.shape[0] == 2 * n and prio.max() > 0
+        # weights the other way (Learner_mp.py:124-130 -> Actor_mp.py:133-144): one RCCL broadcast of the flat vector
+        from torch.nn.utils import parameters_to_vector
+        torch.manual_seed(3)
+        model = T.NN_11(d, 3).to(dev)
+        w0 = parameters_to_vector(model.parameters()).detach().clone()
+        buf = gather.broadcast_weights(model, src=0)
+        torch.cuda.synchronize()
+        assert buf.is_cuda and buf.numel() == w0.numel() > 800000 and torch.equal(buf, w0)
+        assert torch.equal(parameters_to_vector(model.parameters()).detach(), w0)
         gpu.close()
     finally:
         dist.destroy_process_group()

@@ -28,14 +28,17 @@ def computePrioritiesParallel(A, R, Q, Qns, discount):
 
 
 def run_actor(envs, model, n_flushes, size_local_memory_buffer, epsilon, discount_factor=0.95, sink=None,
-              chunk=1 << 16):
+              chunk=1 << 16, weight_sync=None):
     """Runs `n_flushes` buffer flushes of the actor loop on `envs` (an EnvSet with numpy_io=False,
     already reset).  Yields one TransitionBlock per flush: no_envs * size_local_memory_buffer
     transitions in slot order t * no_envs + e with their priorities in the block's priority section
     (tq_block_priorities = computePrioritiesParallel on the device, f64 arithmetic stored as f32).
     As upstream, the local buffer has one extra column whose transition is dropped at the flush
     (local_buffer_T[:, :-1], Actor_mp.py:67,146-152): that step is taken, its q_values close the
-    priorities of the column before it, and its transition is not recorded."""
+    priorities of the column before it, and its transition is not recorded.
+    ``weight_sync``: called with the model when the buffer is full, before the priorities and the send --
+    where upstream loads the learner's new weights (Actor_mp.py:133-144); on N>1 pass
+    ``lambda m: gather.broadcast_weights(m, src=learner_rank)``."""
     assert not envs.numpy_io, "run_actor needs an EnvSet with numpy_io=False"
     n, dev = envs.no_envs, envs.device
     T = int(size_local_memory_buffer)
@@ -47,6 +50,8 @@ def run_actor(envs, model, n_flushes, size_local_memory_buffer, epsilon, discoun
             act, qv = selectActionEnvSet(envs, model, epsilon, chunk=chunk)
             Q[t] = qv
             envs.actorStep(act, block=blk if t < T else None, slot=t)
+        if weight_sync is not None:
+            weight_sync(model)
         blk.computePriorities(n, T, Q, discount_factor)
         if sink is not None:
             sink(blk)

@@ -258,6 +258,13 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
     h->num_cus = g_ctx[device].num_cus;
+    // set-up calls allocate AND synchronise (toricenv.h): the memsets above ran on the null stream, and a
+    // caller's non-blocking stream does not order itself behind that -- the first kernel of a fresh handle
+    // (k_reset reads episodes / mark) must find them zero.
+    if (hipError_t se = hipStreamSynchronize(nullptr); se != hipSuccess) {
+        tq_destroy(h);
+        return fail(TQ_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(se));
+    }
     *out = h;
     return TQ_OK;
 }
@@ -275,8 +282,11 @@ int tq_destroy(tq_env* h) {
 
 int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int max_steps_per_episode) {
     if (!h) return fail(TQ_E_INVALID, "NULL handle");
-    // p_error = 0 can never produce a defect: every reset would spin through MAX_RESET_ROUNDS rounds
-    if (!(p_error_default > 0.0 && p_error_default <= 1.0)) return fail(TQ_E_INVALID, "p_error must be in (0,1]");
+    // p_error = 0 can never produce a defect: every reset would spin through MAX_RESET_ROUNDS rounds.  With the
+    // fixed-n sampler (min_qubit_errors > 0, set first) p_error is not used at all and 0 is accepted.
+    const bool p_unused = h->min_err > 0;
+    if (!((p_error_default > 0.0 || (p_unused && p_error_default == 0.0)) && p_error_default <= 1.0))
+        return fail(TQ_E_INVALID, "p_error must be in (0,1] (0 is accepted only with min_qubit_errors > 0)");
     if (max_steps_per_episode < 1) return fail(TQ_E_INVALID, "max_steps_per_episode must be >= 1");
     h->sched.p_default = p_error_default;
     h->terminal_reward = terminal_reward;
@@ -287,6 +297,8 @@ int tq_set_params(tq_env* h, double p_error_default, double terminal_reward, int
 int tq_set_min_qubit_errors(tq_env* h, int n_errors) {
     if (!h) return fail(TQ_E_INVALID, "NULL handle");
     if (n_errors < 0 || n_errors > 2 * h->d * h->d) return fail(TQ_E_INVALID, "min_qubit_errors must be in [0, 2*d*d]");
+    if (n_errors == 0 && !(h->sched.p_default > 0.0))
+        return fail(TQ_E_INVALID, "min_qubit_errors = 0 selects the depolarizing sampler, which needs p_error in (0,1]");
     h->min_err = n_errors;
     return TQ_OK;
 }

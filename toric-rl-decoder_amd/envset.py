@@ -20,7 +20,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, wire
 from ._lib import TQ_BF16, TQ_F16, TQ_F32, TQ_U8, check
 
 _DTYPES = {torch.float32: TQ_F32, torch.float16: TQ_F16, torch.bfloat16: TQ_BF16, torch.uint8: TQ_U8}
@@ -74,6 +74,7 @@ class ToricEnv:
         self.device = device
         self.seed = int(seed)
         self._set = None
+        self._scratch = None
 
     def _envs(self):
         if self._set is None:
@@ -101,9 +102,10 @@ class ToricEnv:
 
     def createSyndromOpt(self, qubit_matrix):
         d = self.system_size
-        scratch = EnvSet(self, 1, device=self.device, seed=self.seed)
-        scratch.setQubits(np.asarray(qubit_matrix).reshape(1, 2, d, d))
-        return scratch.getStates()[0]
+        if self._scratch is None:                              # one scratch lattice, created once (11 hipMallocs)
+            self._scratch = EnvSet(self, 1, device=self.device, seed=self.seed)
+        self._scratch.setQubits(np.asarray(qubit_matrix).reshape(1, 2, d, d))
+        return self._scratch.getStates()[0]
 
     @staticmethod
     def isTerminalState(state):
@@ -168,12 +170,7 @@ class TransitionBlock:
                                                   _ptr(q_values), float(discount), _stream()))
 
 
-def transition_dtype(size):
-    """The reference's replay record (Actor_mp.py:52-56, util.py:10)."""
-    action_type = np.dtype([('position', (np.int64, 3)), ('op', np.int64)])
-    return np.dtype([('perspective', (np.int64, (2, size, size))), ('action', action_type),
-                     ('reward', np.float64), ('next_perspective', (np.int64, (2, size, size))),
-                     ('terminal', np.bool_)])
+transition_dtype = wire.transition_type     # the reference's replay record (Actor_mp.py:52-56, util.py:10)
 
 
 def to_structured(unpacked, size):
@@ -216,10 +213,12 @@ class EnvSet:
         with torch.cuda.device(self.device):
             check(self._L.tq_create(C.byref(self._h), self.no_envs, self.size, self.device.index,
                                     C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), self.first_env_id))
-        check(self._L.tq_set_params(self._h, self.p_error, self.terminal_reward, self.max_steps_per_episode))
-        # gym config "min_qubit_errors" (always 0 in the reference's own configs): n > 0 = fixed-n sampler
+        # gym config "min_qubit_errors" (always 0 in the reference's own configs): n > 0 = fixed-n sampler,
+        # which does not use p_error -- set first, so that {min_qubit_errors: n, p_error: 0} is a valid config
         self.min_qubit_errors = int(getattr(env, "min_qubit_errors", 0))
-        check(self._L.tq_set_min_qubit_errors(self._h, self.min_qubit_errors))
+        if self.min_qubit_errors > 0:
+            check(self._L.tq_set_min_qubit_errors(self._h, self.min_qubit_errors))
+        check(self._L.tq_set_params(self._h, self.p_error, self.terminal_reward, self.max_steps_per_episode))
         n, d, dev = self.no_envs, self.size, self.device
         self._state_u8 = torch.zeros((n, 2, d, d), dtype=torch.uint8, device=dev)
         self._rewards = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -384,7 +383,7 @@ class EnvSet:
         -> (perspectives (P,2,d,d), positions (P,3), counts (N,)).
         Reads P back from the device (one 8-byte copy), like the reference's data-dependent shape."""
         if states is not None:
-            out, pos, counts = generatePerspectiveBatch(self.size // 2, self.size, states, dtype=dtype, device=self.device)
+            out, pos, counts = generatePerspectiveBatch(self.size // 2, self.size, states, dtype=dtype, device=self.device)[:3]
             if self.numpy_io:
                 return out.cpu().numpy(), pos.cpu().numpy().astype(np.int64), counts.cpu().numpy().astype(np.int64)
             return out, pos, counts
@@ -469,10 +468,12 @@ def _reserve_states(dev, d, n):
         _reserved[key] = n                                # the scratch only ever grows
 
 
-def generatePerspectiveBatch(grid_shift, toric_size, states, dtype=torch.float32, device=None):
+def generatePerspectiveBatch(grid_shift, toric_size, states, dtype=torch.float32, device=None, return_offsets=False):
     """numba/util_actor.py:56-67 for syndromes that do not live in an EnvSet (e.g. the learner's
     next_state batch, util_learner.py:48-111).  states: (n,2,d,d) numpy / tensor.
-    -> (perspectives (P,2,d,d) tensor, positions (P,3) i32 tensor, counts (n,) i32 tensor)."""
+    -> (perspectives (P,2,d,d) tensor, positions (P,3) i32 tensor, counts (n,) i32 tensor)
+    [+ offsets (n+1,) i64 tensor, the exclusive scan the kernels produced, with ``return_offsets``].
+    One 8-byte read-back of P (the output shape is data dependent, as upstream)."""
     dev = _require_gpu(device)
     if int(grid_shift) != int(toric_size) // 2:
         raise ValueError("grid_shift must be int(toric_size/2) (Actor_mp.py:59)")
@@ -484,14 +485,19 @@ def generatePerspectiveBatch(grid_shift, toric_size, states, dtype=torch.float32
     offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
     _reserve_states(dev, d, n)
     with torch.cuda.device(dev):
-        check(L.tq_states_persp_count(d, n, _ptr(st), _ptr(counts), _ptr(offsets), _stream()))
+        rc = L.tq_states_persp_count(d, n, _ptr(st), _ptr(counts), _ptr(offsets), _stream())
+        if rc == _lib.TQ_E_CAPACITY:                           # the python-side record of the scratch size was stale
+            _reserved.pop((dev.index, d), None)
+            _reserve_states(dev, d, n)
+            rc = L.tq_states_persp_count(d, n, _ptr(st), _ptr(counts), _ptr(offsets), _stream())
+        check(rc)
         P = int(offsets[-1].item())
         out = torch.empty((P, 2, d, d), dtype=dtype, device=dev)
         pos = torch.empty((P, 3), dtype=torch.int32, device=dev)
         if P:
             check(L.tq_states_persp_write(d, n, _ptr(st), _ptr(offsets), _ptr(out), _ptr(pos), P, _DTYPES[dtype],
                                           _stream()))
-    return out, pos, counts
+    return (out, pos, counts, offsets) if return_offsets else (out, pos, counts)
 
 
 def generateTransitionParallel(action, reward, state, next_state, terminal_state, grid_shift, trans_type=None,

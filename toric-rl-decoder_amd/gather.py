@@ -7,11 +7,42 @@ one fixed-size packed transition block per flush; rank 0 receives all of them in
 ring that stays in its HBM (288 GB: ~7e9 transitions at d=7), so nothing crosses PCIe per step.
 Lattices never interact, so this gather is the ONLY collective of the path.
 
+The other direction is the weights: the learner publishes the flattened parameter vector
+(Learner_mp.py:124-130, ~0.9 M f32 = 3.6 MB for NN_11) and every actor loads it at its next flush
+(Actor_mp.py:133-144; MPI variant: comm.bcast, mpi/Actor_mpi.py:84) -> :func:`broadcast_weights`,
+ONE broadcast per flush.
+
 Backend "nccl" is RCCL on ROCm (device buffers, xGMI point-to-point fan-in to the root);
 "gloo" (CPU tests, world_size 2) stages the same bytes through host tensors.
 """
 import torch
 import torch.distributed as dist
+from torch.nn.utils import parameters_to_vector, vector_to_parameters
+
+
+def broadcast_weights(model, src=0, group=None, buffer=None):
+    """Learner -> actors, once per flush: rank ``src`` flattens its parameters (parameters_to_vector,
+    Learner_mp.py:124), ONE ``dist.broadcast`` of the f32 vector (RCCL over xGMI; gloo on the CPU), every other
+    rank loads it with vector_to_parameters (Actor_mp.py:143).  The reference's shared array is float64 and the
+    actor casts back to FloatTensor: f32 -> f64 -> f32 is the identity, so sending f32 is bit-identical.
+    ``buffer``: optional reusable f32 staging vector (returned; allocated on first use).  Enqueues on the
+    current stream for nccl (no host synchronisation); parameters only, like upstream (no module buffers)."""
+    params = list(model.parameters())
+    if not params:
+        return buffer
+    backend = dist.get_backend(group)
+    dev = params[0].device
+    stage = dev if backend == "nccl" else torch.device("cpu")
+    n = sum(p.numel() for p in params)
+    if buffer is None or buffer.numel() != n or buffer.device != stage or buffer.dtype != torch.float32:
+        buffer = torch.empty(n, dtype=torch.float32, device=stage)
+    with torch.no_grad():
+        if dist.get_rank(group) == src:
+            buffer.copy_(parameters_to_vector(params).detach().to(torch.float32))
+        dist.broadcast(buffer, src=src, group=group)
+        if dist.get_rank(group) != src:
+            vector_to_parameters(buffer.to(device=dev, dtype=params[0].dtype), params)
+    return buffer
 
 
 def shard_range(total_envs, world_size, rank):
@@ -57,6 +88,11 @@ class TransitionGather:
         self.host_ring = None
         self._copy_stream = None
         self._drained = []
+        # The collective is issued from a stream of its own (nccl): it waits for the env stream (the block is
+        # complete) and for the ring slot's previous D2H copy, so a slow PCIe drain holds back the next gather into
+        # that slot -- never the env kernels on the compute stream.
+        self._coll_stream = torch.cuda.Stream(device=self.device) if self.stage_device.type == "cuda" else None
+        self._ready = torch.cuda.Event() if self._coll_stream is not None else None
         if host_drain and self.is_root and self.stage_device.type == "cuda":
             self.host_ring = torch.empty((self.ring_slots, self.world, self.nbytes), dtype=torch.uint8).pin_memory()
             self._copy_stream = torch.cuda.Stream(device=self.device)
@@ -80,9 +116,15 @@ class TransitionGather:
         mine = self.rank == root
         src = buf if buf.device == self.stage_device else buf.to(self.stage_device)
         outs = [self.ring[slot, r] for r in range(self.world)] if mine else None
-        if mine and self.host_ring is not None and use >= self.ring_slots:
-            torch.cuda.current_stream(self.device).wait_event(self._drained[slot])   # slot still being copied out?
-        work = dist.gather(src, gather_list=outs, dst=root, group=self.group, async_op=True)
+        if self._coll_stream is not None:
+            self._ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._coll_stream):
+                self._coll_stream.wait_event(self._ready)
+                if mine and self.host_ring is not None and use >= self.ring_slots:
+                    self._coll_stream.wait_event(self._drained[slot])             # slot still being copied out?
+                work = dist.gather(src, gather_list=outs, dst=root, group=self.group, async_op=True)
+        else:
+            work = dist.gather(src, gather_list=outs, dst=root, group=self.group, async_op=True)
         self._pending.append((work, src))
         if mine and self.host_ring is not None:
             with torch.cuda.stream(self._copy_stream):
@@ -99,6 +141,8 @@ class TransitionGather:
 
     def wait(self):
         self._drain(0)
+        if self._coll_stream is not None:
+            self._coll_stream.synchronize()
         if self._copy_stream is not None:
             self._copy_stream.synchronize()
         if self.device.type == "cuda":

@@ -95,11 +95,9 @@ def selectActionBatch(number_of_actions, epsilon, grid_shift, toric_size, state,
     if dev.type != "cuda":
         raise ValueError("device must be a cuda (ROCm) device: the toric env has no CPU path")
     model.eval()
-    persp, pos, counts = generatePerspectiveBatch(grid_shift, toric_size, state, device=dev)
+    persp, pos, counts, offsets = generatePerspectiveBatch(grid_shift, toric_size, state, device=dev, return_offsets=True)
     dev = persp.device
     n = int(counts.numel())
-    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, out=offsets[1:])
     q = _forward_chunked(model, persp, chunk)
     eps = torch.as_tensor(np.array(np.broadcast_to(np.asarray(epsilon, np.float64), (n,))), device=dev)   # writable copy
     actions = torch.empty((n, 4), dtype=torch.int32, device=dev)
@@ -127,9 +125,8 @@ def predictMaxOptimized(model, batch_state, grid_shift, system_size, device, chu
     """util_learner.py:48-111: max Q-value of every state of the batch (0 for terminal states),
     perspectives generated and reduced on the device.  -> float32 tensor (n,) on ``device``."""
     model.eval()
-    persp, pos, counts = generatePerspectiveBatch(grid_shift, system_size, batch_state, device=device)
-    offsets = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=persp.device)
-    torch.cumsum(counts, 0, out=offsets[1:])
+    persp, pos, counts, offsets = generatePerspectiveBatch(grid_shift, system_size, batch_state, device=device,
+                                                           return_offsets=True)
     q = _forward_chunked(model, persp, chunk)
     # the reference gives a terminal state one dummy perspective (:74-76), which counts for the padding
     largest = torch.clamp(counts.max(), min=1).to(torch.int32).reshape(1)

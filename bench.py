@@ -49,6 +49,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
+# the stack-write kernel libtoricenv launches (TORIC_STACK_KERNEL=lattice selects the one-wave-per-lattice form for A/B runs)
+STACK_KERNEL = "k_persp_write" if os.environ.get("TORIC_STACK_KERNEL") == "lattice" else "k_persp_stream"
 EPISODE = 76                    # a lattice is auto-reset once its step counter exceeds 75 (Distributed_mp.py:44)
 ENVS_N1, ENVS_MULTI = 65536, 131072     # BASELINE configs[2] / configs[4] lattices per GPU
 NN_CHUNK = 16384                # perspectives per NN_11 forward call
@@ -80,7 +82,7 @@ def parse(argv=None):
                          "the ~63 GB/s of packed records; 1 below)")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
-    ap.add_argument("--nn-steps", type=int, default=1,
+    ap.add_argument("--nn-steps", type=int, default=3,
                     help="N=1: timed steps of the NN_11-in-the-loop leg (configs[2] as written); 0 = skip")
     ap.add_argument("--no-shard-leg", action="store_true",
                     help="N=1: skip the extra timing of the N>1 per-GPU shape (131072 lattices); profiling runs use this "
@@ -181,18 +183,20 @@ class Shard:
     """One sub-shard of this GPU's lattices with its stream and its caller-owned output buffers."""
 
 
-def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm):
-    """The same pass over a batch of `n` lattices on the current stream, no events, no collective:
-    burn-in, `warm` untimed and `steps` timed steps.  -> (seconds, perspectives in the timed steps).
-    Used at N=1 to time one GPU on the per-GPU shape of the N>1 runs (configs[4]: 131 072 lattices), so
-    the scaling curve can be read like for like."""
+def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False):
+    """The same pass over a batch of `n` lattices on the current stream, no collective: burn-in, `warm` untimed
+    and `steps` timed steps.  -> (seconds, perspectives in the timed steps, per-step stack-write milliseconds
+    from HIP events or None).  Used at N=1 for the extra legs of the line: one GPU on the per-GPU shape of the
+    N>1 runs (configs[4]: 131 072 lattices) and BASELINE configs[3] (65 536 lattices, d=9, p=0.15), one shot
+    and with the stack written in `chunks` lattice ranges into a buffer of 1/chunks the size."""
     nq = 2 * d * d
     envs = T.EnvSet(env, n, device=device, seed=seed, first_env_id=first, numpy_io=False)
     envs.resetAll()
-    stack = torch.empty((n * nq, 2, d, d), dtype=tdtype, device=device)
-    positions = torch.empty((n * nq, 3), dtype=torch.int32, device=device)
+    stack = torch.empty(((n // chunks) * nq, 2, d, d), dtype=tdtype, device=device)
+    positions = torch.empty(((n // chunks) * nq, 3), dtype=torch.int32, device=device)
     offs = torch.zeros((warm + steps, (n + 2) & ~1), dtype=torch.int64, device=device)
     blocks = [envs.newTransitionBlock(steps=flush) for _ in range(2)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if events else None
     for t in range(EPISODE):
         idx = torch.arange(t, n, EPISODE, dtype=torch.int32, device=device)
         if idx.numel():
@@ -202,7 +206,15 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
     def step(t):
         off = offs[t][:n + 1]
         envs.perspectiveCounts(off)
-        envs.writePerspectives(stack, positions, off)
+        if ev is not None and t >= warm:
+            ev[t - warm][0].record()
+        if chunks == 1:
+            envs.writePerspectives(stack, positions, off)
+        else:
+            for c in range(chunks):
+                envs.writePerspectives(stack, positions, off, first=c * (n // chunks), count=n // chunks)
+        if ev is not None and t >= warm:
+            ev[t - warm][1].record()
         blk = blocks[(t // flush) & 1]
         envs.actorStep(None, block=blk, slot=t % flush, want_actions=True)
         if (t + 1) % flush == 0:
@@ -219,7 +231,50 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
     P = float(offs[warm:, n].sum().item())
     envs.check()
     envs.close()
-    return dt, P
+    ev_ms = np.array([a.elapsed_time(b) for a, b in ev]) if ev is not None else None
+    return dt, P, ev_ms
+
+
+def load_trained_weights(d):
+    """The reference's trained NN_11 state_dict for size d, committed as a data fixture (tests/golden/nn11_d*.safetensors,
+    made by tests/golden/make_weights.py from network/converged/*.pt with weights_only=True), or None."""
+    path = os.path.join(ROOT, "tests", "golden", "nn11_d%d_converged.safetensors" % d)
+    if not os.path.exists(path):
+        return None
+    from safetensors.torch import load_file
+    return load_file(path)
+
+
+def config_name(world, n, d, p):
+    """Which BASELINE.json config a (lattices per GPU, d, p_error) triple is -- by all three, not by n alone."""
+    if d == 7 and abs(p - 0.10) < 1e-12:
+        if n == ENVS_N1 and world == 1:
+            return "configs[2]"
+        if n == ENVS_MULTI:
+            return "configs[4] shape"
+    if d == 9 and abs(p - 0.15) < 1e-12 and n == ENVS_N1 and world == 1:
+        return "configs[3]"
+    if d == 5 and abs(p - 0.10) < 1e-12 and n == 4096 and world == 1:
+        return "configs[1]"
+    return "custom"
+
+
+def pmc_traffic(d, out_dtype, n, p_error, launches_per_step, p_mean):
+    """HBM bytes per launch from the committed counters of a PROFILED run of the same shape
+    (profiles/pmc_latest.json: separate --pmc passes, WRITE_SIZE + 2*FETCH_SIZE, tools/pmc_profile.sh), scaled by
+    this run's perspectives per launch.  None unless lattice size, dtype, lattices, p_error and launch shape all
+    match: the counters are not collected in this process, so they are only quoted for the run they describe."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if launches_per_step != 1 or not os.path.exists(pmc):
+        return None, None
+    try:
+        for ent in json.load(open(pmc)).get("entries", []):
+            if (ent.get("d") == d and ent.get("out_dtype") == out_dtype and ent.get("envs") == n
+                    and abs(ent.get("p_error", -1) - p_error) < 1e-12):
+                return ent["hbm_bytes_per_perspective"] * p_mean, ent
+    except Exception:
+        pass
+    return None, None
 
 
 def dry_run(args, world, rank, result_out):
@@ -332,7 +387,7 @@ def main():
             sh.envs.resetAll()
             sh.stack = torch.empty((cap, 2, d, d), dtype=tdtype, device=device)
             sh.positions = torch.empty((cap, 3), dtype=torch.int32, device=device)
-            sh.offs = torch.zeros((2 * (W + K) + args.nn_steps + 2, row), dtype=torch.int64, device=device)  # one scan per step: P = row[ns]
+            sh.offs = torch.zeros((2 * (W + K) + 2 * args.nn_steps + 4, row), dtype=torch.int64, device=device)  # one scan per step: P = row[ns]
             sh.blocks = None if args.no_transitions else [sh.envs.newTransitionBlock(steps=flush) for _ in range(2)]
             sh.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                      for _ in range(K)] if use_events else []
@@ -487,45 +542,82 @@ def main():
     shard_leg = None
     if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore" and not args.no_shard_leg:
         k2, w2 = max(8, min(K, 40)), 8
-        dt2, P2 = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2)
+        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
                      "perspectives_per_sec": P2 / dt2,
                      "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
                              "no collective: the like-for-like base of the scaling curve"}
 
-    # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured once at size
+    # ---- N=1 on the default shape: BASELINE configs[3] (65 536 lattices, d=9, p=0.15) timed by this very run,
+    # one shot and with the stack written in 4 lattice ranges into a buffer of a quarter of the size
+    c3_leg = None
+    if (world == 1 and not dist_on and args.envs is None and d == 7 and graph is None and args.policy == "explore"
+            and not args.no_shard_leg and args.out_dtype == "f32"):
+        d3, p3, n3, k3, w3 = 9, 0.15, ENVS_N1, max(8, min(K, 20)), 5
+        env3 = T.make("toric-code-v0", {"size": d3, "min_qubit_errors": 0, "p_error": p3})
+        c3_leg = {"workload": "BASELINE configs[3]: %d lattices, d=%d, p_error=%g, f32 stack; same actor-loop pass" % (n3, d3, p3),
+                  "steps": k3, "warmup": w3}
+        for name, ch in (("one_shot", 1), ("chunks_4", 4)):
+            dt3, P3, ev3 = time_plain_loop(T, torch, env3, n3, d3, args.seed, 0, tdtype, flush, device, k3, w3, chunks=ch, events=True)
+            alg3 = P3 / k3 * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
+            c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
+                            "perspectives_per_sec": P3 / dt3, "perspectives_per_lattice": P3 / (k3 * n3),
+                            "roofline": {"bound": "hbm", "kernel": STACK_KERNEL, "achieved": alg3 / (ev3.mean() * 1e-3) / 1e9,
+                                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg3 / (ev3.mean() * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                         "bytes_per_step": alg3, "avg_write_ms_per_step": float(ev3.mean()),
+                                         "launches_per_step": ch,
+                                         "note": "HIP events around the stack write(s) of every timed step%s" %
+                                                 ("" if ch == 1 else ": the %d range launches, their gaps and k_split included" % ch)}}
+
+    # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured at size in
+    # f32 (what upstream runs) and with the bf16 stack the kernels can write directly + bf16 autocast
     nn_leg = None
     if world == 1 and args.nn_steps > 0 and args.policy == "explore" and graph is None and S == 1 and CH == 1:
-        state["tg"], state["model"] = None, make_model()
         sh0 = shards[0]
-        base = W + K
-        print("[bench] nn_in_loop leg: warm-up step (MIOpen picks its kernels) ...", file=sys.stderr, flush=True)
-        t0 = time.perf_counter()
-        one_step(0, base)                                             # warm-up: MIOpen picks its kernels
-        torch.cuda.synchronize(device)
-        print("[bench] nn_in_loop leg: warm-up took %.1f s; timing %d step(s) ..." % (time.perf_counter() - t0, args.nn_steps),
-              file=sys.stderr, flush=True)
-        t0 = time.perf_counter()
-        for i in range(args.nn_steps):
-            one_step(0, base + 1 + i)
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
-        P_nn = float(sh0.offs[base + 1:base + 1 + args.nn_steps, ns].sum().item())
         flop_per_persp = 2.0 * sum(ci * co * 9 * ((d - 2) ** 2 if i == 10 else d * d)
                                    for i, (ci, co) in enumerate(zip((2, 128, 128, 120, 111, 104, 103, 90, 80, 73, 71),
                                                                     (128, 128, 120, 111, 104, 103, 90, 80, 73, 71, 64))))
-        nn_leg = {"workload": "configs[2] as written: %d lattices, d=%d: stack (%s) -> NN_11 (random init, %s, stock torch "
-                              "conv) -> device eps=%g greedy selection -> fused step" % (n, d, args.out_dtype, args.nn_dtype, args.eps),
-                  "steps": args.nn_steps, "env_steps_per_sec": n * args.nn_steps / dt,
-                  "perspectives_per_sec_into_nn": P_nn / dt, "ms_per_step": 1e3 * dt / args.nn_steps,
-                  "nn_dtype": args.nn_dtype, "nn_tflops": P_nn * flop_per_persp / dt / 1e12}
-        state["model"] = None
-        sh0.envs.check()
+        weights = load_trained_weights(d)
+        nn_leg = {"workload": "configs[2] as written: %d lattices, d=%d: stack -> NN_11 (%s, stock torch conv) -> device "
+                              "eps=%g greedy selection -> fused step" %
+                              (n, d, "the reference's trained d=%d weights" % d if weights is not None else "random init", args.eps),
+                  "steps": args.nn_steps, "variants": {}}
+        base = W + K
+        for vname, nn_dtype in (("f32", "f32"), ("bf16", "bf16")):
+            m = make_model()
+            if weights is not None:
+                m.load_state_dict(weights)
+            stack_save = sh0.stack
+            if nn_dtype == "bf16":                                    # the stack written as bf16 by the kernel itself (TQ_BF16)
+                sh0.stack = torch.empty(sh0.stack.shape, dtype=torch.bfloat16, device=device)
+            state["tg"], state["model"], args.nn_dtype = None, m, nn_dtype
+            print("[bench] nn_in_loop %s: warm-up step (MIOpen picks its kernels) ..." % vname, file=sys.stderr, flush=True)
+            t0 = time.perf_counter()
+            one_step(0, base)
+            torch.cuda.synchronize(device)
+            print("[bench] nn_in_loop %s: warm-up took %.1f s; timing %d step(s) ..." % (vname, time.perf_counter() - t0, args.nn_steps),
+                  file=sys.stderr, flush=True)
+            t0 = time.perf_counter()
+            for i in range(args.nn_steps):
+                one_step(0, base + 1 + i)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            P_nn = float(sh0.offs[base + 1:base + 1 + args.nn_steps, ns].sum().item())
+            nn_leg["variants"][vname] = {"stack_dtype": "bf16" if nn_dtype == "bf16" else args.out_dtype, "nn_dtype": nn_dtype,
+                                         "env_steps_per_sec": n * args.nn_steps / dt, "perspectives_per_sec_into_nn": P_nn / dt,
+                                         "ms_per_step": 1e3 * dt / args.nn_steps, "nn_tflops": P_nn * flop_per_persp / dt / 1e12}
+            base += 1 + args.nn_steps
+            sh0.stack = stack_save
+            state["model"] = None
+            del m
+            sh0.envs.check()
+        for k_ in ("env_steps_per_sec", "perspectives_per_sec_into_nn", "ms_per_step", "nn_tflops", "nn_dtype"):
+            nn_leg[k_] = nn_leg["variants"]["f32"][k_]                # top level = the f32 run, as upstream
 
     if rank == 0:
         policy_txt = "policy NN excluded (eps=1 selection in the fused kernel)" if model is None else \
             "NN_11 (random init, %s) forward + eps=%g greedy selection IN the loop" % (args.nn_dtype, args.eps)
-        cfg_name = "configs[2]" if (world == 1 and n == ENVS_N1) else ("configs[4] shape" if n == ENVS_MULTI else "custom")
+        cfg_name = config_name(world, n, d, args.p_error)
         collective = None
         if dist_on:
             collective = "transition gather (packed blocks incl. priorities) to %s (%s, %d ranks) every %d steps%s" % (
@@ -553,24 +645,13 @@ def main():
             res["hbm_ring"] = hbm_ring
         if shard_leg is not None:
             res["configs4_shard_on_one_gpu"] = shard_leg
+        if c3_leg is not None:
+            res["configs3_on_one_gpu"] = c3_leg
         if use_events:
             p_mean = float(p_timed.mean().item())
             alg = p_mean * (nq * esize + 12) + ns * nq                 # P*(B_p+12) + N*2d^2, per launch
             achieved = alg / (ev_ms.mean() * 1e-3) / 1e9
-            # HBM bytes from the PMC counters: profiles/pmc_latest.json holds the counters of a profiled run
-            # (tools/pmc_profile.sh: separate --pmc passes, WRITE_SIZE + 2*FETCH_SIZE in KiB units) as bytes per
-            # PERSPECTIVE of that run; scaled by this run's perspectives per launch when shape and dtype match
-            traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-            if os.path.exists(pmc):
-                try:
-                    j = json.load(open(pmc))
-                    for ent in j.get("entries", []):
-                        if ent.get("d") == d and ent.get("out_dtype") == args.out_dtype:
-                            traffic = ent["hbm_bytes_per_perspective"] * p_mean
-                            traffic_src = ent.get("source")
-                except Exception:
-                    traffic = None
+            traffic, ent = pmc_traffic(d, args.out_dtype, n, args.p_error, S * CH, p_mean)
             # context: the box's own streaming-fill bandwidth, measured after the timed region
             # on the same buffer (hipMemsetAsync through torch), so frac can be read against it as well
             fb = shards[0].stack.view(torch.uint8).reshape(-1)[:int(alg) & ~4095]
@@ -580,10 +661,12 @@ def main():
                 f0.record(); fb.zero_(); f1.record(); f1.synchronize()
                 fill_ms.append(f0.elapsed_time(f1))
             fill_gbps = fb.numel() / (min(fill_ms[1:]) * 1e-3) / 1e9
-            res["roofline"] = {"bound": "hbm", "kernel": "k_persp_write", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            res["roofline"] = {"bound": "hbm", "kernel": STACK_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                                "traffic_over_algorithmic": None if traffic is None else traffic / alg,
-                               "traffic_source": traffic_src,
+                               "traffic_from_profile_run": None if ent is None else True,
+                               "traffic_source": None if ent is None else "%s; counters of the profiled run %s, not of this process" % (
+                                   ent.get("source"), ent.get("profiled_at", "profiles/pmc_latest.json")),
                                "measured_fill_gbps": fill_gbps, "frac_of_measured_fill": achieved / fill_gbps,
                                "bytes_per_launch": alg, "avg_launch_ms": float(ev_ms.mean()),
                                "median_launch_ms": float(np.median(ev_ms)), "perspectives_per_launch": p_mean,

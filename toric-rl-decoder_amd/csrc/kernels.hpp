@@ -589,6 +589,8 @@ __global__ __launch_bounds__(256) void k_block_priorities(BlockView b, int64_t n
 // (8 per thread, two int4 loads), adds the partials before its chunk (<= N/256 values, one strided
 // wave reduction) and writes the offsets.
 constexpr int SCAN_CHUNK = 2048;
+constexpr int WIN_LOG = 13;                                    // stack window of the windowed write: 8192 elements
+constexpr int PWIN_LOG = 13;                                   // positions window: 8192 dwords
 
 __device__ __forceinline__ int64_t wave_sum64(int64_t x) {
 #pragma unroll
@@ -613,11 +615,18 @@ __global__ __launch_bounds__(256) void k_scan_partials(const int32_t* __restrict
     block_count_partial(e < N ? counts[e] : 0, part256);
 }
 
+// `split` (may be NULL): cut points of the batch into G = 1 << LG parts of equal perspective count for the
+// stack write (stream_write.hpp): split[k] = first lattice e with offsets[e] >= (P * k) >> LG, k = 0..G.
+// A by-product of the scan: every thread knows the offsets around its eight lattices, the workgroup sums all
+// level-1 partials for P, and the thread whose interval holds a cut point writes it.
+// `widx` / `pidx` (may be NULL): window index of the stack write (window_write.hpp), another by-product: lattice e owns
+// the stack windows (8192 elements) and positions windows (8192 dwords) that START inside its perspectives.
 __global__ __launch_bounds__(256) void k_scan_final(const int32_t* __restrict__ counts, const int64_t* __restrict__ partial,
                                                     int64_t* __restrict__ offsets, int32_t* __restrict__ counts_out,
-                                                    int64_t N) {
+                                                    int64_t N, int32_t* __restrict__ split, int LG,
+                                                    int32_t* __restrict__ widx = nullptr, int32_t* __restrict__ pidx = nullptr, int nq = 0) {
     __shared__ int64_t ws[4];
-    __shared__ int64_t base_s;
+    __shared__ int64_t base_s, total_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i0 = (int64_t)blockIdx.x * SCAN_CHUNK + tid * 8;
     int c[8];
@@ -638,13 +647,21 @@ __global__ __launch_bounds__(256) void k_scan_final(const int32_t* __restrict__ 
         b = wave_sum64(b);
         if (lane == 0) base_s = b;
     }
+    if (wave == 1 && split) {                                 // P = sum of all partials
+        int64_t b = 0;
+        const int nparts = (int)((N + PART_BLOCK - 1) / PART_BLOCK);
+        for (int j = lane; j < nparts; j += 64) b += partial[j];
+        b = wave_sum64(b);
+        if (lane == 0) total_s = b;
+    }
     __syncthreads();
     int64_t run = base_s + inc - mine;
     for (int w = 0; w < wave; ++w) run += ws[w];
-    if (i0 + 8 <= N) {
-        int64_t o[8];
+    int64_t o[9];
+    o[0] = run;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { o[k] = run; run += c[k]; }
+    for (int k = 0; k < 8; ++k) o[k + 1] = o[k] + c[k];       // counts past N were loaded as 0
+    if (i0 + 8 <= N) {
         longlong2* dst = reinterpret_cast<longlong2*>(offsets + i0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) dst[k] = make_longlong2(o[2 * k], o[2 * k + 1]);
@@ -652,15 +669,52 @@ __global__ __launch_bounds__(256) void k_scan_final(const int32_t* __restrict__ 
             *reinterpret_cast<int4*>(counts_out + i0) = make_int4(c[0], c[1], c[2], c[3]);
             *reinterpret_cast<int4*>(counts_out + i0 + 4) = make_int4(c[4], c[5], c[6], c[7]);
         }
-        if (i0 + 8 == N) offsets[N] = run;
+        if (i0 + 8 == N) offsets[N] = o[8];
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (i0 + k < N) {
-                offsets[i0 + k] = run;
+                offsets[i0 + k] = o[k];
                 if (counts_out) counts_out[i0 + k] = c[k];
-                run += c[k];
-                if (i0 + k + 1 == N) offsets[N] = run;
+                if (i0 + k + 1 == N) offsets[N] = o[k + 1];
+            }
+        }
+    }
+    if (widx) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (c[k] > 0) {
+                const int32_t e = (int32_t)(i0 + k);
+                for (int64_t w = (o[k] * nq + (1 << WIN_LOG) - 1) >> WIN_LOG; w < ((o[k + 1] * nq + (1 << WIN_LOG) - 1) >> WIN_LOG); ++w) widx[w] = e;
+                if (pidx) for (int64_t w = (o[k] * 3 + (1 << PWIN_LOG) - 1) >> PWIN_LOG; w < ((o[k + 1] * 3 + (1 << PWIN_LOG) - 1) >> PWIN_LOG); ++w) pidx[w] = e;
+            }
+        }
+    }
+    if (split) {
+        const int64_t total = total_s;
+        const int G = 1 << LG;
+        if (total == 0) {                                     // empty stack: any valid table will do
+            if (blockIdx.x == 0) for (int k = tid; k <= G; k += 256) split[k] = 0;
+        } else {
+            if (blockIdx.x == 0 && tid == 0) split[0] = 0;
+            if (o[8] > o[0]) {
+                // kfloor(x) = the largest k with T_k = (total * k) >> LG <= x: float estimate, exact fix-up
+                auto T = [&](int64_t k) { return (int64_t)(((uint64_t)total * (uint64_t)k) >> LG); };
+                auto kfloor = [&](int64_t x) {
+                    int64_t k = (int64_t)((double)(x + 1) * (double)G / (double)total);
+                    k = k < 0 ? 0 : (k > G ? G : k);
+                    while (k < G && T(k + 1) <= x) ++k;
+                    while (k > 0 && T(k) > x) --k;
+                    return k;
+                };
+                const int64_t kA = kfloor(o[0]) + 1, kB = kfloor(o[8]);
+                for (int64_t k = kA; k <= kB; ++k) {          // cut points inside (o[0], o[8]]: usually none, rarely one
+                    const int64_t t = T(k);
+                    int j = 0;
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) j += o[q] < t;        // smallest j with o[j+1] >= t
+                    split[k] = (int32_t)(i0 + j + 1);
+                }
             }
         }
     }

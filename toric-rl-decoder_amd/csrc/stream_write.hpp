@@ -1,0 +1,404 @@
+// Perspective stack write, producer / storer form (gfx950 / CDNA4).
+//
+// One persistent workgroup per CU owns a CONTIGUOUS range of the output (lattices [e_lo, e_hi), cut so
+// that every workgroup gets the same number of perspectives, k_scan_final / k_split).  Inside the workgroup
+// the two jobs of the stack write are done by different waves:
+//   * NP producer waves build lattice bitstreams (lattice.hpp, PStream: rotated planes by ballot, table of
+//     row-rolled planes, one lane per hit, ds_or_b32) -- not into a per-wave buffer but into ONE ring in LDS
+//     that is the workgroup's output range as a bit string (bit x = element org + x of the stack);
+//   * NS storer waves do nothing but  ds_read_b32 -> shift -> bit->element expansion -> global_store_dwordx4
+//     along that range, in aligned windows of CPW KiB, and hand the ring words back zeroed;
+//   * one wave writes the positions (P,3) from a second ring (one packed dword per perspective).
+// Hand-off: `prod` (perspectives committed, in lattice order), `cons[s]` (low-water mark of storer s), `pcons`:
+// plain LDS words, release/acquire at workgroup scope, polled with s_sleep.  Every poll loop is bounded; a wave
+// that gives up raises `abort` for its workgroup and latches ERR_INTERNAL, so the grid always drains.
+//
+// Output lines: the stack is cut into 128-byte lines and a workgroup stores the lines whose FIRST element lies
+// in its range, whole.  The trailing elements of its last line belong to the first lattice(s) of the next
+// range: its producers simply go on for the few perspectives that line needs (`need_extra`).
+#pragma once
+#include "kernels.hpp"
+#include "window_write.hpp"
+
+namespace tq {
+
+constexpr int STREAM_SPIN_LIMIT = 1 << 21;
+
+template <int D>
+struct ProdTables {                                            // private to one producer wave
+    static constexpr int NQP = (Lat<D>::NQ + 7) & ~7;
+    uint64_t rr[4][D][Lat<D>::W];                              // V, P, rot V, rot P rolled by every row amount
+    uint64_t low[D][Lat<D>::W];                                // lowcols(k)
+    uint32_t hpos[NQP];                                        // k-th hit -> layer | row << 8 | col << 16
+};
+
+template <int D, int NS, int NP, int RB_LOG, int RP_LOG>
+struct StreamLds {
+    __attribute__((aligned(16))) uint32_t bits[1u << RB_LOG];  // the output range as a bit string, ring
+    uint32_t posr[1u << RP_LOG];                               // packed position of perspective q at [q & mask]
+    ProdTables<D> tab[NP];
+    uint32_t prod;                                             // perspectives committed so far (range-relative)
+    uint32_t cons[NS];                                         // storer s: first element (from org) it has not taken yet
+    uint32_t pcons;                                            // perspectives whose positions are written
+    uint32_t abort;
+};
+
+// The cut points of a lattice range into G parts of equal perspective count: split[k] = the first lattice
+// e in [e_begin, e_end] with offsets[e] - offsets[e_begin] >= (total * k) >> LG.  One wavefront per cut
+// point, 64-ary search (three rounds for 65 536 lattices).  k_scan_final writes the same table for the whole
+// batch as a by-product; this kernel serves lattice sub-ranges and offsets that did not come from the scan.
+__global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offsets, int64_t e_begin, int64_t e_end,
+                                               int32_t* __restrict__ split, int LG) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int G = 1 << LG;
+    if (k > G) return;
+    const int64_t off0 = offsets[e_begin], total = offsets[e_end] - off0;
+    const int64_t target = off0 + (int64_t)(((uint64_t)total * (uint64_t)k) >> LG);
+    int64_t lo = e_begin, hi = e_end;                         // answer in [lo, hi]; offsets[hi] >= target always
+    while (lo < hi) {
+        const int64_t span = hi - lo;
+        const int64_t stepw = (span + 63) / 64;               // probes lo + i*stepw, i = 0..63 (the last ones clamp to hi)
+        int64_t e = lo + (int64_t)lane * stepw;
+        e = e < hi ? e : hi;
+        const bool ge = offsets[e] >= target;
+        const uint64_t m = __ballot(ge);                      // never empty: the clamped lanes probe hi
+        const int f = (int)__ffsll((long long)m) - 1;
+        int64_t ef = lo + (int64_t)f * stepw;
+        ef = ef < hi ? ef : hi;
+        const int64_t new_lo = f == 0 ? lo : (lo + (int64_t)(f - 1) * stepw + 1);
+        if (ef == lo) { hi = lo; break; }
+        lo = new_lo < ef ? new_lo : ef;
+        hi = ef;
+    }
+    if (lane == 0) split[k] = (int32_t)lo;
+}
+
+// STATS (diagnostic builds only, tools/stream_bench.hip): every wave leaves {cycles alive, cycles waiting (A), cycles
+// waiting (B), items} in stats[(block * waves + wave) * 4 ..]; A/B = storers: production / -, producers: ring room / commit turn.
+template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false>
+__global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint64_t* __restrict__ vp, int64_t N,
+                                                                  const int64_t* __restrict__ offsets, OutT* __restrict__ out,
+                                                                  int32_t* __restrict__ pos, int64_t capacity,
+                                                                  int* __restrict__ err, int64_t e_begin, int64_t e_end,
+                                                                  const int32_t* __restrict__ split,
+                                                                  unsigned long long* __restrict__ stats = nullptr) {
+    using L = Lat<D>;
+    using PS = PStream<D>;
+    unsigned long long t_begin = 0, t_a = 0, t_b = 0, n_items = 0;
+    if (STATS) t_begin = __builtin_readcyclecounter();
+    auto stats_out = [&](int wv, int ln) {
+        if (STATS && ln == 0) {
+            unsigned long long* o = stats + ((size_t)blockIdx.x * (NS + 1 + NP) + wv) * 4;
+            o[0] = __builtin_readcyclecounter() - t_begin; o[1] = t_a; o[2] = t_b; o[3] = n_items;
+        }
+    };
+    using Enc = OutEnc<OutT>;
+    using B = typename L::B;
+    constexpr int DD = L::DD, NQ = L::NQ, W = L::W;
+    constexpr int VEC = 16 / (int)sizeof(OutT);              // elements per 16-byte lane store
+    constexpr int EPC = 64 * VEC;                            // elements per chunk (one wave store instruction = 1 KiB)
+    constexpr int LE = 128 / (int)sizeof(OutT);              // elements per 128-byte line
+    constexpr int LPD = 32 / VEC;                            // lanes that share one ring dword
+    constexpr uint32_t RING_BITS = 32u << RB_LOG, BMASK = (1u << RB_LOG) - 1u;
+    constexpr uint32_t RP = 1u << RP_LOG, PMASK = RP - 1u;
+    static_assert((uint32_t)NQ * NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS, "bit ring too small for this lattice size");
+    static_assert((uint32_t)NQ + 512u < RP, "position ring too small");
+    __shared__ StreamLds<D, NS, NP, RB_LOG, RP_LOG> S;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+    // ---- this workgroup's range (wave-uniform, scalar)
+    int64_t e_lo = split[blockIdx.x], e_hi = split[blockIdx.x + 1];
+    const int64_t off0 = offsets[e_begin];
+    int64_t p_all = offsets[e_end] - off0;                   // perspectives of the whole stack
+    int64_t e_stop = e_end;                                  // lattices from e_stop on are not written
+    if (p_all > capacity) {                                  // stack does not fit: only the lattices that fit whole are written
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, ERR_CAPACITY);
+        int64_t lo = e_begin, hi = e_end;                    // largest e with offsets[e] - off0 <= capacity
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (offsets[mid] - off0 <= capacity) lo = mid; else hi = mid - 1;
+        }
+        e_stop = lo;
+        p_all = offsets[e_stop] - off0;
+        e_lo = e_lo < e_stop ? e_lo : e_stop;
+        e_hi = e_hi < e_stop ? e_hi : e_stop;
+    }
+    const int64_t Q0 = offsets[e_lo] - off0, Q1 = offsets[e_hi] - off0;        // perspective range [Q0, Q1)
+    const bool last = Q1 >= p_all;                           // no perspective behind this range
+    const int64_t S0 = Q0 * NQ, S1 = Q1 * NQ;                // element range
+    const int64_t org = S0 / LE * LE;                        // ring bit x <-> stack element org + x
+    const uint32_t head = (uint32_t)(S0 - org);
+    const uint32_t a0 = head ? (uint32_t)LE : 0u;            // first element (from org) this workgroup stores
+    int64_t A1 = (S1 + LE - 1) / LE * LE;                    // the line that holds the end of the range is stored whole ...
+    if (last || A1 > p_all * NQ) A1 = p_all * NQ;            // ... unless the stack ends inside it
+    const uint32_t a1 = A1 > org ? (uint32_t)(A1 - org) : 0u;                  // one past the last
+    // positions: dwords, 3 per perspective, lines of 32
+    const int64_t porg = Q0 * 3 / 32 * 32;
+    const uint32_t phead = (uint32_t)(Q0 * 3 - porg);
+    const uint32_t pa0 = phead ? 32u : 0u;
+    int64_t PA1 = (Q1 * 3 + 31) / 32 * 32;
+    if (last || PA1 > p_all * 3) PA1 = p_all * 3;
+    const uint32_t pa1 = PA1 > porg ? (uint32_t)(PA1 - porg) : 0u;
+    // perspectives behind Q1 that the last stack line / positions line of this range needs
+    int64_t need_extra = 0;
+    if (!last) {
+        const int64_t ne_s = (A1 - S1 + NQ - 1) / NQ, ne_p = (PA1 - Q1 * 3 + 2) / 3;
+        need_extra = ne_s > ne_p ? ne_s : ne_p;
+        if (!pos) need_extra = ne_s;
+    }
+    const bool has_stack = a1 > a0, has_pos = pos != nullptr && pa1 > pa0;
+    if (!has_stack && !has_pos) return;                      // uniform over the workgroup
+
+    // ---- ring and hand-off words
+    for (uint32_t i = threadIdx.x; i < (1u << RB_LOG) / 4; i += blockDim.x) reinterpret_cast<uint4*>(S.bits)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x == 0) { S.prod = 0u; S.pcons = 0u; S.abort = 0u; }
+    if (threadIdx.x < NS) S.cons[threadIdx.x] = a0;
+    __syncthreads();
+
+    // bounded wait: until pred(), false when the workgroup gave up
+    auto give_up = [&]() {
+        if (lane == 0) { __hip_atomic_store(&S.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(err, ERR_INTERNAL); }
+    };
+
+    if (wave < NS) {
+        // =========================================================== stack storer
+        if (!has_stack) return;
+        __builtin_amdgcn_s_setprio(3);                       // store issue goes before the producers' arithmetic
+        const int s = wave;
+        constexpr int U = CPW < 4 ? CPW : 4;                 // chunks per trip: one LDS round trip and one hand-back per U KiB
+        static_assert(CPW % U == 0, "window must be a whole number of trips");
+        const uint32_t nchunks = (a1 - a0 + EPC - 1) / EPC;
+        const uint32_t lane_el = (uint32_t)lane * VEC;
+        const int sh = (int)((a0 + lane_el) & 31u);          // a0 is a multiple of LE, EPC of 32: loop-invariant
+        const bool zero_lane = (lane % LPD) == 0;
+        char* __restrict__ obase = reinterpret_cast<char*>(out + org);
+        uint32_t prod_c = 0;                                 // cached S.prod
+        bool first = true;
+        for (uint32_t w = (uint32_t)s; w * CPW < nchunks; w += NS) {
+            for (uint32_t cb = w * CPW; cb < (w + 1) * CPW && cb < nchunks; cb += U) {
+                const uint32_t el0 = a0 + cb * EPC;
+                uint32_t end = el0 + U * EPC;
+                end = end < a1 ? end : a1;
+                if (head + prod_c * (uint32_t)NQ < end) {     // wait until the trip's last element is produced
+                    bool ok = false;
+                    unsigned long long t0 = 0;
+                    if (STATS) t0 = __builtin_readcyclecounter();
+                    for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
+                        prod_c = lds_peek(S.prod);
+                        if (head + prod_c * (uint32_t)NQ >= end) { ok = true; break; }
+                        if (lds_peek(S.abort)) return;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    if (!ok) { give_up(); return; }
+                    lds_after_peek();
+                    if (STATS) t_a += __builtin_readcyclecounter() - t0;
+                }
+                if (STATS) ++n_items;
+                if (first) {
+                    first = false;
+                    if (s == 0 && a0 && lane < (int)(a0 / 32u)) S.bits[lane] = 0u;   // ring words in front of a0 (stored by the previous range)
+                }
+                uint32_t wv[U], idx[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    idx[u] = ((el0 + (uint32_t)u * EPC + lane_el) >> 5) & BMASK;
+                    wv[u] = S.bits[idx[u]];
+                }
+                if (zero_lane) {                             // hand the words back zeroed
+#pragma unroll
+                    for (int u = 0; u < U; ++u) S.bits[idx[u]] = 0u;
+                }
+                if (el0 + U * EPC <= a1) {                   // whole trip inside the range: U x 1 KiB
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        *reinterpret_cast<u32x4*>(obase + (size_t)(el0 + (uint32_t)u * EPC + lane_el) * sizeof(OutT)) = expand_bits<OutT>(wv[u] >> sh);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t el = el0 + (uint32_t)u * EPC + lane_el;
+                        const u32x4 val = expand_bits<OutT>(wv[u] >> sh);
+                        if (el + VEC <= a1) {
+                            *reinterpret_cast<u32x4*>(obase + (size_t)el * sizeof(OutT)) = val;
+                        } else if (el < a1) {                // the stack ends inside this lane's 16 bytes (last range only)
+                            const int nel = (int)(a1 - el);
+                            if (Enc::BITS == 32) {
+                                for (int j = 0; j < nel; ++j) reinterpret_cast<uint32_t*>(obase)[el + j] = val[j];
+                            } else if (Enc::BITS == 16) {
+                                for (int j = 0; j < nel; ++j) reinterpret_cast<uint16_t*>(obase)[el + j] = (uint16_t)(val[j >> 1] >> (16 * (j & 1)));
+                            } else {
+                                for (int j = 0; j < nel; ++j) reinterpret_cast<uint8_t*>(obase)[el + j] = (uint8_t)(val[j >> 2] >> (8 * (j & 3)));
+                            }
+                        }
+                    }
+                }
+                // first element this storer has not taken yet: the next trip of this window, or the next window of its own
+                uint32_t nb = cb + U;
+                if (nb % CPW == 0) nb += (uint32_t)(NS - 1) * CPW;
+                lds_publish(S.cons[s], nb < nchunks ? a0 + nb * EPC : 0xFFFFFFFFu, lane);
+            }
+        }
+        lds_publish(S.cons[s], 0xFFFFFFFFu, lane);
+        stats_out(wave, lane);
+        return;
+    }
+
+    if (wave == NS) {
+        // =========================================================== positions storer
+        if (!has_pos) return;
+        int32_t* __restrict__ pbase = pos + porg;
+        const uint32_t nchunks = (pa1 - pa0 + 255u) / 256u;
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            const uint32_t x0 = pa0 + c * 256u;
+            const uint32_t x_end = x0 + 256u < pa1 ? x0 + 256u : pa1;
+            const uint32_t need = (x_end - phead + 2u) / 3u;
+            bool ok = false;
+            unsigned long long t0 = 0;
+            if (STATS) { t0 = __builtin_readcyclecounter(); ++n_items; }
+            for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
+                if (lds_peek(S.prod) >= need) { ok = true; break; }
+                if (lds_peek(S.abort)) return;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (!ok) { give_up(); return; }
+            lds_after_peek();
+            if (STATS) t_a += __builtin_readcyclecounter() - t0;
+            const uint32_t x = x0 + 4u * (uint32_t)lane;
+            if (x < x_end) {
+                int o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t t = x + j - phead, q = t / 3u;
+                    o[j] = (int)((S.posr[q & PMASK] >> (8u * (t - 3u * q))) & 255u);
+                }
+                if (x + 4u <= x_end) *reinterpret_cast<int4*>(pbase + x) = make_int4(o[0], o[1], o[2], o[3]);
+                else for (uint32_t j = 0; x + j < x_end; ++j) pbase[x + j] = o[j];
+            }
+            lds_publish(S.pcons, (x_end - phead) / 3u, lane);
+        }
+        stats_out(wave, lane);
+        return;
+    }
+
+    // =============================================================== producer
+    const int p = wave - NS - 1;
+    ProdTables<D>& T = S.tab[p];
+    if (lane < D) {                                          // column masks: the same for every lattice
+        const B m = L::lowcols(lane);
+#pragma unroll
+        for (int w = 0; w < W; ++w) T.low[lane][w] = m.w[w];
+    }
+    const int64_t QT = Q1 + need_extra;                      // lattices are produced while they start in front of QT
+    uint32_t lw_c = a0, pc_c = 0u;                           // cached low-water marks of the storers
+    for (int64_t Lb = 0;; Lb += 64 * NP) {
+        // the planes and offsets of this wave's next 64 lattices in one round of vector loads
+        const int64_t e_l = e_lo + Lb + (int64_t)lane * NP + p;
+        const bool in = e_l < e_stop;
+        uint64_t vv[W], pp[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            vv[k] = in ? vp[(int64_t)k * N + e_l] : 0ull;
+            pp[k] = in ? vp[((int64_t)W + k) * N + e_l] : 0ull;
+        }
+        const int64_t oo = in ? offsets[e_l] - off0 : (int64_t)0x7fffffffffffffffll;
+        const uint64_t inmask = __ballot(in && oo < QT);     // offsets are monotone: a prefix of the lanes
+        if (!inmask) break;
+        const int cnt = __popcll(inmask);
+        for (int j = 0; j < cnt; ++j) {
+            B v, pl, e0, e1;
+#pragma unroll
+            for (int k = 0; k < W; ++k) { v.w[k] = readlane64(vv[k], j); pl.w[k] = readlane64(pp[k], j); }
+            L::hit_masks(v, pl, e0, e1);
+            const int n0 = e0.popc();
+            const int n = n0 + e1.popc();
+            if (n == 0) continue;
+            const uint32_t q0 = (uint32_t)((int64_t)readlane64((uint64_t)oo, j) - Q0);
+            const uint32_t bit0 = head + q0 * (uint32_t)NQ, bit1 = bit0 + (uint32_t)n * NQ;
+            // ---- room in the rings: everything below the storers' low-water mark has been handed back.  The marks
+            // are cached: while the storers keep up the ring is nearly empty and one look lasts for dozens of lattices.
+            if (STATS) ++n_items;
+            if (!((lw_c == 0xFFFFFFFFu || bit1 + 64u <= lw_c + RING_BITS) && (!has_pos || q0 + (uint32_t)n <= pc_c + RP))) {
+                bool ok = false;
+                unsigned long long t0 = 0;
+                if (STATS) t0 = __builtin_readcyclecounter();
+                for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
+                    uint32_t c = 0xFFFFFFFFu;
+                    if (has_stack && lane < NS) c = __hip_atomic_load(&S.cons[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (int o = 1; o < NS; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)c, o, 64); c = t < c ? t : c; }
+                    lw_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                    pc_c = has_pos ? lds_peek(S.pcons) : 0u;
+                    if ((lw_c == 0xFFFFFFFFu || bit1 + 64u <= lw_c + RING_BITS) && (!has_pos || q0 + (uint32_t)n <= pc_c + RP)) { ok = true; break; }
+                    if (lds_peek(S.abort)) return;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (!ok) { give_up(); return; }
+                lds_after_peek();
+                if (STATS) t_a += __builtin_readcyclecounter() - t0;
+            }
+            // ---- tables: rotated planes (ballot), row-rolled planes, hit list
+            B rv, rp;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const int o = 64 * k + lane;
+                const bool inb = o < DD;
+                const int oc = inb ? o : 0;
+                rv.w[k] = __ballot(inb && v.get(PS::rot_src_v(oc)));
+                rp.w[k] = __ballot(inb && pl.get(PS::rot_src_p(oc)));
+            }
+            if (lane < 4 * D) {
+                const int sel = lane / D, k = lane - sel * D;
+                B src;
+#pragma unroll
+                for (int w = 0; w < W; ++w) src.w[w] = sel == 0 ? v.w[w] : (sel == 1 ? pl.w[w] : (sel == 2 ? rv.w[w] : rp.w[w]));
+                const B r = (src.shl(k * D) | src.shr(DD - k * D)) & L::full();
+#pragma unroll
+                for (int w = 0; w < W; ++w) T.rr[sel][k][w] = r.w[w];
+            }
+            for (int c = lane; c < NQ; c += 64) {
+                const int l = c >= DD, bit = c - l * DD;
+                if (l ? e1.get(bit) : e0.get(bit)) {
+                    const int row = bit / D, col = bit - row * D;
+                    const int k = l ? n0 + e1.rank(bit) : e0.rank(bit);
+                    const uint32_t hp = (uint32_t)l | ((uint32_t)row << 8) | ((uint32_t)col << 16);
+                    T.hpos[k] = hp;
+                    if (has_pos) S.posr[(q0 + (uint32_t)k) & PMASK] = hp;
+                }
+            }
+            wave_lds_sync();
+            // ---- one lane per hit: its perspective as two bit-planes, OR-ed into the ring
+            for (int k = lane; k < n; k += 64) {
+                const uint32_t hp = T.hpos[k];
+                const int layer = (int)(hp & 255u), i = (int)((hp >> 8) & 255u), jj = (int)(hp >> 16);
+                int rs, cs;
+                PS::hit_shifts(layer, i, jj, rs, cs);
+                B a, c, low;
+#pragma unroll
+                for (int w = 0; w < W; ++w) { a.w[w] = T.rr[2 * layer][rs][w]; c.w[w] = T.rr[2 * layer + 1][rs][w]; low.w[w] = T.low[cs][w]; }
+                const B ov = PS::roll_cols_masked(a, cs, low), op = PS::roll_cols_masked(c, cs, low);
+                if (has_stack)
+                    emit_at<D>(bit0 + (uint32_t)k * NQ, ov, op, [&](uint32_t idx, uint32_t val) { atomicOr(&S.bits[idx & BMASK], val); });
+            }
+            // ---- commit in lattice order
+            {
+                bool ok = false;
+                unsigned long long t0 = 0;
+                if (STATS) t0 = __builtin_readcyclecounter();
+                for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
+                    if (lds_peek(S.prod) == q0) { ok = true; break; }
+                    if (lds_peek(S.abort)) return;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!ok) { give_up(); return; }
+                if (STATS) t_b += __builtin_readcyclecounter() - t0;
+                lds_publish(S.prod, q0 + (uint32_t)n, lane);
+            }
+            wave_lds_sync();                                 // T is rewritten by the next lattice
+        }
+        if (cnt < 64) break;
+    }
+    stats_out(wave, lane);
+}
+
+}  // namespace tq

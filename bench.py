@@ -49,8 +49,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
-# the stack-write kernel libtoricenv launches (TORIC_STACK_KERNEL=lattice selects the one-wave-per-lattice form for A/B runs)
-STACK_KERNEL = "k_persp_write" if os.environ.get("TORIC_STACK_KERNEL") == "lattice" else "k_persp_stream"
+STACK_KERNEL = "k_persp_stream"  # the stack-write kernel libtoricenv launches (csrc/stream_write.hpp)
 EPISODE = 76                    # a lattice is auto-reset once its step counter exceeds 75 (Distributed_mp.py:44)
 ENVS_N1, ENVS_MULTI = 65536, 131072     # BASELINE configs[2] / configs[4] lattices per GPU
 NN_CHUNK = 16384                # perspectives per NN_11 forward call
@@ -86,7 +85,7 @@ def parse(argv=None):
                     help="N=1: timed steps of the NN_11-in-the-loop leg (configs[2] as written); 0 = skip")
     ap.add_argument("--no-shard-leg", action="store_true",
                     help="N=1: skip the extra timing of the N>1 per-GPU shape (131072 lattices); profiling runs use this "
-                         "so that every k_persp_write launch of the process has the headline shape")
+                         "so that every k_persp_stream launch of the process has the headline shape")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
     ap.add_argument("--graph", action="store_true",
                     help="capture --flush steps in a HIP graph and replay it (launch-bound small batches; implies "
@@ -542,6 +541,7 @@ def main():
     shard_leg = None
     if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore" and not args.no_shard_leg:
         k2, w2 = max(8, min(K, 40)), 8
+        print("[bench] configs[4] shard leg (131072 lattices on this GPU) ...", file=sys.stderr, flush=True)
         dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
                      "perspectives_per_sec": P2 / dt2,
@@ -558,6 +558,7 @@ def main():
         c3_leg = {"workload": "BASELINE configs[3]: %d lattices, d=%d, p_error=%g, f32 stack; same actor-loop pass" % (n3, d3, p3),
                   "steps": k3, "warmup": w3}
         for name, ch in (("one_shot", 1), ("chunks_4", 4)):
+            print("[bench] configs[3] leg (65536 lattices, d=9, p=0.15), %s ..." % name, file=sys.stderr, flush=True)
             dt3, P3, ev3 = time_plain_loop(T, torch, env3, n3, d3, args.seed, 0, tdtype, flush, device, k3, w3, chunks=ch, events=True)
             alg3 = P3 / k3 * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
             c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
@@ -567,7 +568,7 @@ def main():
                                          "bytes_per_step": alg3, "avg_write_ms_per_step": float(ev3.mean()),
                                          "launches_per_step": ch,
                                          "note": "HIP events around the stack write(s) of every timed step%s" %
-                                                 ("" if ch == 1 else ": the %d range launches, their gaps and k_split included" % ch)}}
+                                                 ("" if ch == 1 else ": the %d range launches and their gaps included (every workgroup finds its own cut points)" % ch)}}
 
     # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured at size in
     # f32 (what upstream runs) and with the bf16 stack the kernels can write directly + bf16 autocast

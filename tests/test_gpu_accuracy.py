@@ -16,6 +16,8 @@ committed d=7 checkpoint 2.5 sigma ABOVE the recorded 0.9094 there (plausibly a 
 """
 import os
 
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")             # no exhaustive solver search per batch shape on a fresh box
+
 import numpy as np
 import pytest
 import torch
@@ -34,7 +36,7 @@ def T():
     return T
 
 
-@pytest.mark.parametrize("d,episodes", [(5, 4000), (7, 3000)])
+@pytest.mark.parametrize("d,episodes", [(5, 4096), (7, 3072)])
 def test_trained_weights_reproduce_recorded_success_rates_on_the_hip_path(T, golden_dir, d, episodes):
     from safetensors.torch import load_file
     model = T.NN_11(d, 3)

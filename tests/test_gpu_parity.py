@@ -740,3 +740,28 @@ def test_fixed_n_sampler_accepts_p_error_zero(T):
     scratch = e1._scratch
     b = e1.createSyndromOpt(np.zeros((2, d, d), np.int64))
     assert e1._scratch is scratch and np.array_equal(a, O.syndrome(qm)) and not b.any()
+
+
+def test_stack_ranges_whose_lattice_count_is_a_multiple_of_64(T):
+    """Lattice ranges of 64, 128, 4096 lattices (the cut-point search of a range probes 64 lattices per round: spans
+    that are multiples of 64 once left the range's last lattice unprobed) -- every range equals its part of the
+    one-shot stack."""
+    d, n = 7, 8256
+    gpu, _ = make_pair(T, d, n, seed=33, numpy_io=False)
+    gpu.resetAll()
+    for _ in range(2):
+        gpu.actorStep(None, want_actions=False)
+    per, pos, cnt = gpu.generatePerspective(dtype=torch.float32)
+    off = gpu._offsets.clone()
+    offh = off.cpu().numpy()
+    nq = 2 * d * d
+    cuts = [0, 64, 192, 4288, 4352, 8256 - 64, 8256]
+    for a, b in zip(cuts, cuts[1:]):
+        k = int(offh[b] - offh[a])
+        buf = torch.full((k * nq + 300,), 7.0, dtype=torch.float32, device=gpu.device)
+        pbuf = torch.full((3 * k + 70,), -5, dtype=torch.int32, device=gpu.device)
+        gpu.writePerspectives(buf[:k * nq].view(k, 2, d, d), pbuf, off, first=a, count=b - a)
+        gpu.check()
+        assert torch.equal(buf[:k * nq], per[offh[a]:offh[b]].reshape(-1)) and bool((buf[k * nq:] == 7).all()), (a, b)
+        assert torch.equal(pbuf[:3 * k], pos[offh[a]:offh[b]].reshape(-1)) and bool((pbuf[3 * k:] == -5).all()), (a, b)
+    gpu.close()

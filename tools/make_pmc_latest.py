@@ -22,7 +22,7 @@ p_launch = b["perspectives_per_lattice"] * cfg["envs_per_gpu"]
 tot = {"WRITE_SIZE": [0.0, 0], "FETCH_SIZE": [0.0, 0]}
 for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(path)):
-        if "k_persp_write" in r["Kernel_Name"] and r["Counter_Name"] in tot:
+        if "k_persp_stream" in r["Kernel_Name"] and r["Counter_Name"] in tot:
             tot[r["Counter_Name"]][0] += float(r["Counter_Value"])
             tot[r["Counter_Name"]][1] += 1
 w = tot["WRITE_SIZE"][0] / max(1, tot["WRITE_SIZE"][1]) * 1024

@@ -1,8 +1,10 @@
-// Stand-alone harness for the two stack-write kernels (one wave per lattice / producer-storer stream) on synthetic
-// syndromes: same inputs, outputs compared, launches timed with HIP events, and the per-role wait statistics of
-// the stream kernel (STATS instantiation).  Build on the GPU box:
-//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -Iinclude -Itoric-rl-decoder_amd/csrc tools/stream_bench.hip -o tools/stream_bench
-//   tools/stream_bench [d=7|9] [lattices=65536] [q=0.29]
+// Stand-alone harness for the stack-write kernel (producer / storer stream, stream_write.hpp) against the round-2
+// kernel (one wave per lattice, tools/lattice_write_r02.hpp) on synthetic syndromes: same inputs, outputs compared
+// dword for dword, launches timed with HIP events on SIX output buffers (the rate depends on where a buffer lies in
+// HBM), a configuration sweep on the fastest and the slowest of them, and the per-role wait statistics of the
+// stream kernel (STATS instantiation).  Build here, run on the GPU box:
+//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -Iinclude -Itoric-rl-decoder_amd/csrc -Itools tools/stream_bench.hip -o tools/stream_bench
+//   tools/stream_bench [d=3..11] [lattices=65536] [q = probability of a defect per check]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -14,6 +16,7 @@
 #include <vector>
 
 #include "stream_write.hpp"
+#include "lattice_write_r02.hpp"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -48,8 +51,7 @@ struct Timer {
 };
 
 template <int D, int NS, int NP, int CPW>
-void stats_run(const char* name, const uint64_t* vp, int64_t N, const int64_t* off, float* out, int32_t* pos, int64_t cap, int* err,
-               const int32_t* split) {
+void stats_run(const uint64_t* vp, int64_t N, const int64_t* off, float* out, int32_t* pos, int64_t cap, int* err, const int32_t* split) {
     constexpr int WV = NS + 1 + NP, G = 256;
     unsigned long long* st;
     CK(hipMalloc(&st, sizeof(unsigned long long) * G * WV * 4));
@@ -59,47 +61,20 @@ void stats_run(const char* name, const uint64_t* vp, int64_t N, const int64_t* o
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)G * WV * 4);
     CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
-    auto agg = [&](int w0, int w1, const char* role) {
+    printf("per-role statistics, NS=%d NP=%d CPW=%d (cycles = s_memtime ticks; a trip = 4 KiB stored, an item of a producer = one lattice):\n", NS, NP, CPW);
+    auto agg = [&](int w0, int w1, const char* role, const char* a_name, const char* b_name) {
         double tot = 0, a = 0, b = 0, items = 0, mx = 0; int n = 0;
         for (int g = 0; g < G; ++g) for (int w = w0; w < w1; ++w) {
             const unsigned long long* o = &h[((size_t)g * WV + w) * 4];
             if (!o[0]) continue;
             tot += o[0]; a += o[1]; b += o[2]; items += o[3]; mx = std::max(mx, (double)o[0]); ++n;
         }
-        if (n) printf("  %-22s %-10s waves %5d  alive %9.0f cyc (max %9.0f)  wait A %5.1f %%  wait B %5.1f %%  items/wave %7.1f  cyc/item (busy) %7.0f\n",
-                      name, role, n, tot / n, mx, 100 * a / tot, 100 * b / tot, items / n, (tot - a - b) / std::max(1.0, items));
+        if (n) printf("  %-10s waves %5d  alive %9.0f cyc (max %9.0f)  waiting for %s %5.1f %%  %s %5.1f %%  items/wave %7.1f  busy cyc/item %7.0f\n",
+                      role, n, tot / n, mx, a_name, 100 * a / tot, b_name, 100 * b / tot, items / n, (tot - a - b) / std::max(1.0, items));
     };
-    agg(0, NS, "storer");
-    agg(NS, NS + 1, "positions");
-    agg(NS + 1, WV, "producer");
-    CK(hipFree(st));
-}
-
-template <int D, int NS, int NP, int K>
-void win_stats_run(const char* name, int G, const uint64_t* vp, int64_t N, const int64_t* off, float* out, int32_t* pos, int64_t cap,
-                   int* err, const int32_t* widx, const int32_t* pidx) {
-    constexpr int WV = NS + 1 + NP;
-    unsigned long long* st;
-    CK(hipMalloc(&st, sizeof(unsigned long long) * G * WV * 4));
-    CK(hipMemset(st, 0, sizeof(unsigned long long) * G * WV * 4));
-    hipLaunchKernelGGL((tq::k_persp_windows<D, float, NS, NP, K, true>), dim3(G), dim3(64 * WV), 0, 0, vp, N, off, out, pos, cap, err,
-                       (int64_t)0, N, widx, pidx, st);
-    CK(hipDeviceSynchronize());
-    std::vector<unsigned long long> h((size_t)G * WV * 4);
-    CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
-    auto agg = [&](int w0, int w1, const char* role) {
-        double tot = 0, a = 0, items = 0, mx = 0; int n = 0;
-        for (int g = 0; g < G; ++g) for (int w = w0; w < w1; ++w) {
-            const unsigned long long* o = &h[((size_t)g * WV + w) * 4];
-            if (!o[0]) continue;
-            tot += o[0]; a += o[1]; items += o[3]; mx = std::max(mx, (double)o[0]); ++n;
-        }
-        if (n) printf("  %-26s %-10s waves %5d  alive %9.0f cyc (max %9.0f)  waiting %5.1f %%  items/wave %7.1f  cyc/item (busy) %7.0f\n",
-                      name, role, n, tot / n, mx, 100 * a / tot, items / n, (tot - a) / std::max(1.0, items));
-    };
-    agg(0, NS, "storer");
-    agg(NS, NS + 1, "positions");
-    agg(NS + 1, WV, "producer");
+    agg(0, NS, "storer", "production", "-");
+    agg(NS, NS + 1, "positions", "production", "-");
+    agg(NS + 1, WV, "producer", "ring room", "commit turn");
     CK(hipFree(st));
 }
 
@@ -118,118 +93,113 @@ int run(int64_t N, double q) {
     int32_t* counts; CK(hipMalloc(&counts, 4 * N + 64));
     int64_t* part; CK(hipMalloc(&part, 8 * ((N + 255) / 256)));
     int64_t* off; CK(hipMalloc(&off, 8 * (N + 2)));
-    int32_t* split; CK(hipMalloc(&split, 4 * 258));
-    int32_t *widx, *pidx;
-    CK(hipMalloc(&widx, 4 * (((size_t)N * NQ * NQ >> tq::WIN_LOG) + 2))); CK(hipMalloc(&pidx, 4 * (((size_t)N * NQ * 3 >> tq::PWIN_LOG) + 2)));
+    int32_t *split, *split2; CK(hipMalloc(&split, 4 * 258)); CK(hipMalloc(&split2, 4 * 258));
     int* err; CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
     hipLaunchKernelGGL(k_counts<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, vp, counts, N, part);
     hipLaunchKernelGGL(tq::k_scan_final, dim3((unsigned)((N + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK)), dim3(256), 0, 0, counts,
-                       (const int64_t*)part, off, (int32_t*)nullptr, N, split, 8, widx, pidx, NQ);
+                       (const int64_t*)part, off, (int32_t*)nullptr, N, split, 8);
+    hipLaunchKernelGGL(tq::k_split, dim3((256 + 1 + 3) / 4), dim3(256), 0, 0, (const int64_t*)off, (int64_t)0, N, split2, 8);
     CK(hipDeviceSynchronize());
+    int32_t hs[257], hs2[257];
+    CK(hipMemcpy(hs, split, 4 * 257, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs2, split2, 4 * 257, hipMemcpyDeviceToHost));
+    printf("cut points: scan by-product %s k_split\n", memcmp(hs, hs2, sizeof(hs)) ? "DIFFERS FROM" : "==");
+    {   // k_split on lattice sub-ranges against the host's own search
+        std::vector<int64_t> ho((size_t)N + 1);
+        CK(hipMemcpy(ho.data(), off, 8 * (N + 1), hipMemcpyDeviceToHost));
+        const int64_t ranges[][2] = {{0, 64}, {64, 192}, {64, 191}, {1, 129}, {128, 256}, {0, 63}, {0, 65}, {4096, 8192}, {16384, 32768}, {5, N}};
+        for (auto& r : ranges) {
+            if (r[1] > N) continue;
+            CK(hipMemset(split2, 0xff, 4 * 258));
+            hipLaunchKernelGGL(tq::k_split, dim3((256 + 1 + 3) / 4), dim3(256), 0, 0, (const int64_t*)off, r[0], r[1], split2, 8);
+            CK(hipMemcpy(hs2, split2, 4 * 257, hipMemcpyDeviceToHost));
+            int nbad = 0, first_bad = -1;
+            for (int k = 0; k <= 256; ++k) {
+                const int64_t target = ho[r[0]] + (((ho[r[1]] - ho[r[0]]) * k) >> 8);
+                int64_t e = r[0];
+                while (ho[e] < target) ++e;
+                if (hs2[k] != e) { if (!nbad) first_bad = k; ++nbad; }
+            }
+            printf("k_split [%lld, %lld): %d of 257 cut points wrong%s\n", (long long)r[0], (long long)r[1], nbad, nbad ? "" : " (ok)");
+            if (nbad) printf("    first wrong k=%d: got %d\n", first_bad, hs2[first_bad]);
+        }
+    }
+    {   // the stack of lattice sub-ranges: stream kernel (cut points from k_split) against the one-wave-per-lattice kernel
+        std::vector<int64_t> ho((size_t)N + 1);
+        CK(hipMemcpy(ho.data(), off, 8 * (N + 1), hipMemcpyDeviceToHost));
+        const int64_t ranges[][2] = {{0, 64}, {64, 192}, {64, 193}, {1, 129}, {4096, 8192}};
+        unsigned long long* badr; CK(hipMalloc(&badr, 8));
+        for (auto& r : ranges) {
+            if (r[1] > N) continue;
+            const int64_t Pr = ho[r[1]] - ho[r[0]];
+            float *a, *b; int32_t *pa, *pb;
+            CK(hipMalloc(&a, (size_t)Pr * NQ * 4 + 4096)); CK(hipMalloc(&b, (size_t)Pr * NQ * 4 + 4096));
+            CK(hipMalloc(&pa, (size_t)Pr * 12 + 4096)); CK(hipMalloc(&pb, (size_t)Pr * 12 + 4096));
+            CK(hipMemset(a, 0x11, (size_t)Pr * NQ * 4)); CK(hipMemset(b, 0x77, (size_t)Pr * NQ * 4));
+            CK(hipMemset(pa, 0x11, (size_t)Pr * 12)); CK(hipMemset(pb, 0x77, (size_t)Pr * 12)); CK(hipMemset(badr, 0, 8));
+            constexpr int WV = 16;
+            unsigned long long* st; CK(hipMalloc(&st, 8 * 256 * WV * 4)); CK(hipMemset(st, 0, 8 * 256 * WV * 4));
+            hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)(r[1] - r[0])), dim3(64), 0, 0, vp, N, off, a, pa, Pr, err, r[0], r[1]);
+            hipLaunchKernelGGL(tq::k_split, dim3((256 + 1 + 3) / 4), dim3(256), 0, 0, (const int64_t*)off, r[0], r[1], split2, 8);
+            hipLaunchKernelGGL((tq::k_persp_stream<D, float, 4, 11, 8, 14, 12, true>), dim3(256), dim3(1024), 0, 0, vp, N, off, b, pb, Pr, err, r[0], r[1], (const int32_t*)split2, st);
+            hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)a, (const uint32_t*)b, Pr * NQ, badr);
+            hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)pa, (const uint32_t*)pb, Pr * 3, badr);
+            unsigned long long nb; CK(hipMemcpy(&nb, badr, 8, hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> hst((size_t)256 * WV * 4);
+            CK(hipMemcpy(hst.data(), st, hst.size() * 8, hipMemcpyDeviceToHost));
+            int alive = 0, lastwg = -1;
+            for (int g = 0; g < 256; ++g) { bool any = false; for (int w = 0; w < WV; ++w) any |= hst[((size_t)g * WV + w) * 4] != 0; if (any) { ++alive; lastwg = g; } }
+            printf("range [%lld, %lld): %lld perspectives, stream vs lattice kernel: %llu differing dwords; workgroups that reported: %d (last %d)\n",
+                   (long long)r[0], (long long)r[1], (long long)Pr, nb, alive, lastwg);
+            // the same with the product instantiation (no statistics)
+            CK(hipMemset(b, 0x77, (size_t)Pr * NQ * 4)); CK(hipMemset(pb, 0x77, (size_t)Pr * 12)); CK(hipMemset(badr, 0, 8));
+            hipLaunchKernelGGL((tq::k_persp_stream<D, float, 4, 11, 8, 14, 12>), dim3(256), dim3(1024), 0, 0, vp, N, off, b, pb, Pr, err, r[0], r[1], (const int32_t*)nullptr, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)a, (const uint32_t*)b, Pr * NQ, badr);
+            hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)pa, (const uint32_t*)pb, Pr * 3, badr);
+            CK(hipMemcpy(&nb, badr, 8, hipMemcpyDeviceToHost));
+            printf("      product instantiation, cut points found in the kernel: %llu differing dwords\n", nb);
+            CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(pa)); CK(hipFree(pb)); CK(hipFree(st));
+        }
+    }
     int64_t P; CK(hipMemcpy(&P, off + N, 8, hipMemcpyDeviceToHost));
     const double bytes = (double)P * (NQ * 4 + 12) + (double)N * NQ;
     printf("d=%d  lattices %lld  perspectives %lld (%.1f per lattice)  algorithmic bytes %.3f GB\n", D, (long long)N, (long long)P, (double)P / N, bytes / 1e9);
-    float *o1, *o2; int32_t *p1, *p2;
-    CK(hipMalloc(&o1, (size_t)P * NQ * 4 + 4096)); CK(hipMalloc(&o2, (size_t)P * NQ * 4 + 4096));
-    CK(hipMalloc(&p1, (size_t)P * 12 + 4096)); CK(hipMalloc(&p2, (size_t)P * 12 + 4096));
-    CK(hipMemset(o1, 0xff, (size_t)P * NQ * 4)); CK(hipMemset(o2, 0x77, (size_t)P * NQ * 4));
-    CK(hipMemset(p1, 0xff, (size_t)P * 12)); CK(hipMemset(p2, 0x77, (size_t)P * 12));
-    auto lattice = [&] { hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, o1, p1, P, err, (int64_t)0, N); };
-#define STREAMK(NS, NP, CPW) [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS, NP, CPW, 14, 12>), dim3(256), dim3(64 * (NS + 1 + NP)), 0, 0, vp, N, off, o2, p2, P, err, (int64_t)0, N, split, (unsigned long long*)nullptr); }
-#define WINK(G, NS, NP, K) [&] { hipLaunchKernelGGL((tq::k_persp_windows<D, float, NS, NP, K>), dim3(G), dim3(64 * (NS + 1 + NP)), 0, 0, vp, N, off, o2, p2, P, err, (int64_t)0, N, widx, pidx, (unsigned long long*)nullptr); }
-    auto s0 = STREAMK(4, 11, 8);
-    auto s1 = WINK(256, 4, 11, 32);
-    auto s2 = WINK(256, 8, 7, 32);
-#define WINJ(G, NS, NP, K, J) [&] { hipLaunchKernelGGL((tq::k_persp_windows<D, float, NS, NP, K, false, J>), dim3(G), dim3(64 * (NS + 1 + NP)), 0, 0, vp, N, off, o2, p2, P, err, (int64_t)0, N, widx, pidx, (unsigned long long*)nullptr); }
-#define WINM(G, NS, NP, K, M) [&] { hipLaunchKernelGGL((tq::k_persp_windows<D, float, NS, NP, K, false, 1, M>), dim3(G), dim3(64 * (NS + 1 + NP)), 0, 0, vp, N, off, o2, p2, P, err, (int64_t)0, N, widx, pidx, (unsigned long long*)nullptr); }
-    auto s3 = WINM(256, 4, 11, 32, 1);
-    auto s4 = WINM(256, 4, 11, 32, 2);
-    auto s7 = WINM(256, 4, 11, 32, 3);
-    auto s8 = WINM(256, 8, 7, 32, 1);
-    auto s9 = WINM(512, 4, 3, 16, 1);
-    auto s10 = WINM(1024, 4, 3, 16, 1);
-    auto s5 = WINK(512, 4, 11, 32);
-    auto s6 = WINK(256, 6, 9, 32);
+    float* ref; int32_t *pref, *p2;
+    CK(hipMalloc(&ref, (size_t)P * NQ * 4 + 4096)); CK(hipMalloc(&pref, (size_t)P * 12 + 4096)); CK(hipMalloc(&p2, (size_t)P * 12 + 4096));
+    hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, ref, pref, P, err, (int64_t)0, N);
+    unsigned long long* bad; CK(hipMalloc(&bad, 8));
     Timer t;
-    lattice(); s1(); CK(hipDeviceSynchronize());
-    unsigned long long* bad; CK(hipMalloc(&bad, 8)); CK(hipMemset(bad, 0, 8));
-    hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, 0, (const uint32_t*)o1, (const uint32_t*)o2, (int64_t)P * NQ, bad);
-    hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)p1, (const uint32_t*)p2, (int64_t)P * 3, bad);
-    unsigned long long nbad; CK(hipMemcpy(&nbad, bad, 8, hipMemcpyDeviceToHost));
-    int e; CK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));
-    printf("stream vs lattice: %llu differing dwords, error latch %d\n", nbad, e);
-    struct V { const char* name; std::vector<float> ms; };
-    std::vector<V> vs = {{"lattice (1 wave/lattice)", {}}, {"stream NS=4 NP=11 CPW=8", {}}, {"windows G=256 NS=4 NP=11", {}},
-                         {"windows G=256 NS=8 NP=7", {}}, {"win 256/4: storers only, const", {}}, {"win 256/4: storers only, LDS", {}},
-                         {"hipMemsetAsync (stack bytes)", {}}, {"windows G=512 NS=4 NP=11", {}}, {"windows G=256 NS=6 NP=9", {}},
-                         {"win 256/4: no positions", {}}, {"win 256/8: storers only, const", {}}, {"win 512/4: storers only, const", {}},
-                         {"win 1024/4: storers only, const", {}}};
-    for (int rep = 0; rep < 12; ++rep) {
-        vs[0].ms.push_back(t.run(lattice));
-        vs[1].ms.push_back(t.run(s0));
-        vs[2].ms.push_back(t.run(s1));
-        vs[3].ms.push_back(t.run(s2));
-        vs[4].ms.push_back(t.run(s3));
-        vs[5].ms.push_back(t.run(s4));
-        vs[6].ms.push_back(t.run([&] { (void)hipMemsetAsync(o2, 1, (size_t)P * NQ * 4, 0); }));
-        vs[7].ms.push_back(t.run(s5));
-        vs[8].ms.push_back(t.run(s6));
-        vs[9].ms.push_back(t.run(s7));
-        vs[10].ms.push_back(t.run(s8));
-        vs[11].ms.push_back(t.run(s9));
-        vs[12].ms.push_back(t.run(s10));
-    }
-    for (auto& v : vs) {
-        std::vector<float> m(v.ms.begin() + 2, v.ms.end());
-        double sum = 0; for (float x : m) sum += x;
-        const double avg = sum / m.size(), best = *std::min_element(m.begin(), m.end());
-        printf("%-30s avg %7.1f us  %6.0f GB/s   best %7.1f us  %6.0f GB/s\n", v.name, 1e3 * avg, bytes / avg / 1e6, 1e3 * best, bytes / best / 1e6);
-    }
-    // H1: does the rate of the stream kernel depend on WHICH buffer it writes (physical placement)?  Then the
-    // configuration sweep on the fastest and on the slowest of six buffers.
-    {
-        std::vector<float*> bufs; std::vector<double> rate;
-        for (int b = 0; b < 6; ++b) { float* x; CK(hipMalloc(&x, (size_t)P * NQ * 4 + 4096 + (size_t)b * (3u << 20))); CK(hipMemset(x, 0, (size_t)P * NQ * 4)); bufs.push_back(x); }
-        auto timeit = [&](auto k) { float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(k); if (r) a += x; } return bytes / (a / 5) / 1e6; };
-        for (int b = 0; b < 6; ++b) {
-            float* ob = bufs[b];
-            auto ks = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, 4, 11, 8, 14, 12>), dim3(256), dim3(1024), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, (unsigned long long*)nullptr); };
-            auto kl = [&] { hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N); };
-            auto km = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 4, 0); };
-            const double rs = timeit(ks), rl = timeit(kl), rm = timeit(km);
-            rate.push_back(rs);
-            printf("  buffer %d at %p: stream %6.0f GB/s   lattice %6.0f GB/s   memset %6.0f GB/s\n", b, (void*)ob, rs, rl, rm * ((double)P * NQ * 4) / bytes);
-        }
-        const int fast = (int)(std::max_element(rate.begin(), rate.end()) - rate.begin()), slow = (int)(std::min_element(rate.begin(), rate.end()) - rate.begin());
-        for (int which : {fast, slow}) {
-            float* ob = bufs[which];
-            printf("  sweep on buffer %d (%s):\n", which, which == fast ? "fastest" : "slowest");
-#define SW(NS, NP, CPW) { auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS, NP, CPW, 14, 12>), dim3(256), dim3(64 * (NS + 1 + NP)), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, (unsigned long long*)nullptr); }; \
-            printf("    NS=%d NP=%2d CPW=%2d  %6.0f GB/s\n", NS, NP, CPW, timeit(k)); }
-            SW(4, 11, 8) SW(2, 13, 8) SW(4, 7, 8) SW(4, 5, 8) SW(4, 3, 8) SW(6, 9, 8) SW(8, 7, 8) SW(3, 6, 8) SW(4, 11, 4) SW(4, 11, 16) SW(4, 11, 32) SW(2, 5, 8) SW(2, 5, 32)
-            auto kl = [&] { hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N); };
-            printf("    lattice            %6.0f GB/s\n", timeit(kl));
-        }
-        for (auto x : bufs) CK(hipFree(x));
-    }
-    // correctness of every windows variant against the lattice kernel
-    int vi = 0;
-    for (auto* f : {(void*)0}) { (void)f; }
-    auto verify = [&](const char* name, auto launch) {
-        CK(hipMemset(o2, 0x77, (size_t)P * NQ * 4)); CK(hipMemset(p2, 0x77, (size_t)P * 12)); CK(hipMemset(bad, 0, 8));
-        launch(); CK(hipDeviceSynchronize());
-        hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, 0, (const uint32_t*)o1, (const uint32_t*)o2, (int64_t)P * NQ, bad);
-        hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)p1, (const uint32_t*)p2, (int64_t)P * 3, bad);
+    auto timeit = [&](auto k) { float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(k); if (r) a += x; } return bytes / (a / 5) / 1e6; };
+    constexpr int NSP = D <= 5 ? 2 : 4, NPP = D <= 5 ? 13 : 11;       // the library's configuration (toricenv.hip)
+    std::vector<float*> bufs; std::vector<double> rate;
+    for (int b = 0; b < 6; ++b) { float* x; CK(hipMalloc(&x, (size_t)P * NQ * 4 + 4096 + (size_t)b * (3u << 20))); bufs.push_back(x); }
+    printf("six output buffers, the same launches on each (GB/s of algorithmic bytes; memset: stack bytes only):\n");
+    for (int b = 0; b < 6; ++b) {
+        float* ob = bufs[b];
+        auto ks = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NSP, NPP, 8, 14, 12>), dim3(256), dim3(64 * (NSP + 1 + NPP)), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, (unsigned long long*)nullptr); };
+        auto kl = [&] { hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N); };
+        auto km = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 4, 0); };
+        CK(hipMemset(ob, 0x77, (size_t)P * NQ * 4)); CK(hipMemset(p2, 0x77, (size_t)P * 12)); CK(hipMemset(bad, 0, 8));
+        ks(); CK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, 0, (const uint32_t*)ref, (const uint32_t*)ob, (int64_t)P * NQ, bad);
+        hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)pref, (const uint32_t*)p2, (int64_t)P * 3, bad);
         unsigned long long nb; CK(hipMemcpy(&nb, bad, 8, hipMemcpyDeviceToHost));
-        int ee; CK(hipMemcpy(&ee, err, 4, hipMemcpyDeviceToHost));
-        printf("  verify %-28s %llu differing dwords, latch %d\n", name, nb, ee);
-        ++vi;
-    };
-    verify("stream", s0); verify("win 256/8/7", s2);  verify("win 512/4/11", s5); verify("win 256/6/9", s6);
-    stats_run<D, 4, 11, 8>("stream NS=4 NP=11 CPW=8", vp, N, off, o2, p2, P, err, split);
-    win_stats_run<D, 4, 11, 32>("windows G=256 NS=4 NP=11", 256, vp, N, off, o2, p2, P, err, widx, pidx);
-    win_stats_run<D, 8, 7, 32>("windows G=256 NS=8 NP=7", 256, vp, N, off, o2, p2, P, err, widx, pidx);
-
+        int e; CK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));
+        const double rs = timeit(ks), rl = timeit(kl), rm = timeit(km) * ((double)P * NQ * 4) / bytes;
+        rate.push_back(rs);
+        printf("  buffer %d: stream %6.0f   one wave per lattice %6.0f   hipMemsetAsync %6.0f   (stream vs lattice: %llu differing dwords, latch %d)\n",
+               b, rs, rl, rm, nb, e);
+    }
+    const int fast = (int)(std::max_element(rate.begin(), rate.end()) - rate.begin()), slow = (int)(std::min_element(rate.begin(), rate.end()) - rate.begin());
+    for (int which : {fast, slow}) {
+        float* ob = bufs[which];
+        printf("storer / producer waves and window size, on buffer %d (%s):\n", which, which == fast ? "fastest" : "slowest");
+#define SW(NS, NP, CPW) { auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS, NP, CPW, 14, 12>), dim3(256), dim3(64 * (NS + 1 + NP)), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, (unsigned long long*)nullptr); }; \
+        printf("    NS=%d NP=%2d CPW=%2d  %6.0f GB/s\n", NS, NP, CPW, timeit(k)); }
+        SW(4, 11, 8) SW(2, 13, 8) SW(4, 7, 8) SW(4, 3, 8) SW(6, 9, 8) SW(8, 7, 8) SW(4, 11, 4) SW(4, 11, 32) SW(2, 5, 8)
+        auto kl = [&] { hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N); };
+        printf("    one wave per lattice %6.0f GB/s\n", timeit(kl));
+    }
+    stats_run<D, NSP, NPP, 8>(vp, N, off, bufs[fast], p2, P, err, split);
     return 0;
 }
 
@@ -237,8 +207,11 @@ int main(int argc, char** argv) {
     const int d = argc > 1 ? atoi(argv[1]) : 7;
     const int64_t N = argc > 2 ? atoll(argv[2]) : 65536;
     const double q = argc > 3 ? atof(argv[3]) : (d == 7 ? 0.29 : 0.31);
+    if (d == 3) return run<3>(N, q);
+    if (d == 5) return run<5>(N, q);
     if (d == 7) return run<7>(N, q);
     if (d == 9) return run<9>(N, q);
-    printf("d must be 7 or 9\n");
+    if (d == 11) return run<11>(N, q);
+    printf("d must be 3, 5, 7, 9 or 11\n");
     return 1;
 }

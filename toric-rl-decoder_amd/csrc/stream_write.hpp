@@ -18,11 +18,46 @@
 // range: its producers simply go on for the few perspectives that line needs (`need_extra`).
 #pragma once
 #include "kernels.hpp"
-#include "window_write.hpp"
 
 namespace tq {
 
+constexpr int ERR_INTERNAL = 32;
 constexpr int STREAM_SPIN_LIMIT = 1 << 21;
+
+// Hand-off words live in LDS, which one workgroup's waves see coherently, and a wave's LDS operations execute in
+// issue order: publishing needs no memory fence, only the COMPILER must keep the order (a workgroup-scope release
+// would also drain vmcnt, i.e. stall a storer on its own global stores); reading needs only the s_waitcnt that the
+// use of the value implies.
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t& w) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void lds_after_peek() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ void lds_publish(uint32_t& w, uint32_t v, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) __hip_atomic_store(&w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// OR the NQ-bit string of one perspective into the ring at bit position `pos` (the caller's orfn reduces the dword
+// index mod the ring)
+template <int D, class OrFn>
+__device__ __forceinline__ void emit_at(uint32_t pos, const typename Lat<D>::B& ov, const typename Lat<D>::B& op, OrFn&& orfn) {
+    using S = PStream<D>;
+    const uint32_t base = pos >> 5;
+    const int sh = (int)(pos & 31);
+    uint32_t prev = 0;
+#pragma unroll
+    for (int j = 0; j <= S::ND; ++j) {
+        const uint32_t cur = j < S::ND ? S::string_dword(ov, op, j) : 0u;
+        const uint32_t val = (cur << sh) | ((prev >> 1) >> (31 - sh));
+        if (j < S::ND || val) orfn(base + j, val);
+        prev = cur;
+    }
+}
 
 template <int D>
 struct ProdTables {                                            // private to one producer wave
@@ -43,26 +78,22 @@ struct StreamLds {
     uint32_t abort;
 };
 
-// The cut points of a lattice range into G parts of equal perspective count: split[k] = the first lattice
-// e in [e_begin, e_end] with offsets[e] - offsets[e_begin] >= (total * k) >> LG.  One wavefront per cut
-// point, 64-ary search (three rounds for 65 536 lattices).  k_scan_final writes the same table for the whole
-// batch as a by-product; this kernel serves lattice sub-ranges and offsets that did not come from the scan.
-__global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offsets, int64_t e_begin, int64_t e_end,
-                                               int32_t* __restrict__ split, int LG) {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int G = 1 << LG;
-    if (k > G) return;
+// A cut point of a lattice range into G = 1 << LG parts of equal perspective count: the first lattice e in
+// [e_begin, e_end] with offsets[e] - offsets[e_begin] >= (total * k) >> LG.  One wavefront, 64-ary search (three
+// rounds of vector loads for 65 536 lattices); the result is wave-uniform.  k_scan_final writes the same numbers for
+// the whole batch as a by-product; this serves lattice sub-ranges and offsets that did not come from the scan.
+__device__ __forceinline__ int64_t find_cut(const int64_t* __restrict__ offsets, int64_t e_begin, int64_t e_end, int k, int LG, int lane) {
     const int64_t off0 = offsets[e_begin], total = offsets[e_end] - off0;
     const int64_t target = off0 + (int64_t)(((uint64_t)total * (uint64_t)k) >> LG);
     int64_t lo = e_begin, hi = e_end;                         // answer in [lo, hi]; offsets[hi] >= target always
     while (lo < hi) {
         const int64_t span = hi - lo;
-        const int64_t stepw = (span + 63) / 64;               // probes lo + i*stepw, i = 0..63 (the last ones clamp to hi)
+        const int64_t stepw = (span + 62) / 63;               // probes lo + i*stepw, i = 0..63: lane 63 reaches hi (63*stepw >= span)
         int64_t e = lo + (int64_t)lane * stepw;
         e = e < hi ? e : hi;
         const bool ge = offsets[e] >= target;
-        const uint64_t m = __ballot(ge);                      // never empty: the clamped lanes probe hi
+        const uint64_t m = __ballot(ge);                      // never empty: lane 63 probes hi
+        if (!m) { lo = hi; break; }
         const int f = (int)__ffsll((long long)m) - 1;
         int64_t ef = lo + (int64_t)f * stepw;
         ef = ef < hi ? ef : hi;
@@ -71,7 +102,16 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offse
         lo = new_lo < ef ? new_lo : ef;
         hi = ef;
     }
-    if (lane == 0) split[k] = (int32_t)lo;
+    return lo;
+}
+// all cut points of a range as a table (tools/stream_bench.hip checks it against the scan's by-product)
+__global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offsets, int64_t e_begin, int64_t e_end,
+                                               int32_t* __restrict__ split, int LG) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k > (1 << LG)) return;
+    const int64_t e = find_cut(offsets, e_begin, e_end, k, LG, lane);
+    if (lane == 0) split[k] = (int32_t)e;
 }
 
 // STATS (diagnostic builds only, tools/stream_bench.hip): every wave leaves {cycles alive, cycles waiting (A), cycles
@@ -108,8 +148,22 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
-    // ---- this workgroup's range (wave-uniform, scalar)
-    int64_t e_lo = split[blockIdx.x], e_hi = split[blockIdx.x + 1];
+    // ---- this workgroup's range (wave-uniform): from the scan's table, or -- split == nullptr: a lattice sub-range, or
+    // offsets that did not come with the scan -- found here by waves 0 and 1 (gridDim.x must be a power of two)
+    int64_t e_lo, e_hi;
+    if (split) {
+        e_lo = split[blockIdx.x]; e_hi = split[blockIdx.x + 1];
+    } else {
+        __shared__ int64_t cut[2];
+        if (wave < 2) {
+            const int64_t e = find_cut(offsets, e_begin, e_end, (int)blockIdx.x + wave, 31 - __clz((int)gridDim.x), lane);
+            if (lane == 0) cut[wave] = e;
+        }
+        __syncthreads();
+        e_lo = cut[0]; e_hi = cut[1];
+    }
+    e_lo = e_lo < e_begin ? e_begin : (e_lo > e_end ? e_end : e_lo);       // whatever the table holds, stay inside the range
+    e_hi = e_hi < e_lo ? e_lo : (e_hi > e_end ? e_end : e_hi);
     const int64_t off0 = offsets[e_begin];
     int64_t p_all = offsets[e_end] - off0;                   // perspectives of the whole stack
     int64_t e_stop = e_end;                                  // lattices from e_stop on are not written

@@ -14,7 +14,6 @@
 
 #include "kernels.hpp"
 #include "stream_write.hpp"
-#include "window_write.hpp"
 
 namespace {
 
@@ -54,7 +53,7 @@ struct DeviceCtx {
     void* ws = nullptr;             // scratch of the tq_states_persp_* entry points (tq_states_reserve)
     size_t ws_bytes = 0;
     int num_cus = 0;
-    int32_t* split = nullptr;       // cut points of the stateless stack write (2 tables of SPLIT_MAX + 2)
+    int32_t* split = nullptr;       // cut points of the stateless stack write, written by the scan
     const int64_t* split_for = nullptr;   // the offsets array the scan's tables were computed for
     int split_n = 0, split_d = 0;         // ... and the batch shape
 };
@@ -121,8 +120,8 @@ int get_lut(int dev, int d, hipStream_t stream, const uint8_t** out) {
         HIPCHECK(hipMemset(c.err, 0, sizeof(int)));
     }
     if (!c.split) {
-        HIPCHECK(hipMalloc((void**)&c.split, 2 * (SPLIT_MAX + 2) * sizeof(int32_t)));
-        HIPCHECK(hipMemset(c.split, 0, 2 * (SPLIT_MAX + 2) * sizeof(int32_t)));
+        HIPCHECK(hipMalloc((void**)&c.split, (SPLIT_MAX + 2) * sizeof(int32_t)));
+        HIPCHECK(hipMemset(c.split, 0, (SPLIT_MAX + 2) * sizeof(int32_t)));
     }
     if (!c.num_cus) {
         hipDeviceProp_t prop;
@@ -134,114 +133,48 @@ int get_lut(int dev, int d, hipStream_t stream, const uint8_t** out) {
 }
 
 int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int64_t* offsets, int32_t* counts_out,
-                int64_t n, hipStream_t stream, int32_t* split, int32_t* widx = nullptr, int32_t* pidx = nullptr, int nq = 0) {
+                int64_t n, hipStream_t stream, int32_t* split) {
     const unsigned blocks = (unsigned)((n + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK);
     if (!partial_valid)
         hipLaunchKernelGGL(tq::k_scan_partials, dim3((unsigned)((n + tq::PART_BLOCK - 1) / tq::PART_BLOCK)), dim3(256), 0,
                            stream, counts, partial, n);
     hipLaunchKernelGGL(tq::k_scan_final, dim3(blocks), dim3(256), 0, stream, counts, (const int64_t*)partial, offsets,
-                       counts_out, n, split, SPLIT_LG, widx, pidx, nq);
+                       counts_out, n, split, SPLIT_LG);
     KCHECK();
     return TQ_OK;
 }
 
-// Which stack-write kernel: "stream" (producer / storer waves, persistent workgroup per CU, stream_write.hpp)
-// or "lattice" (one wave per lattice, kernels.hpp).  TORIC_STACK_KERNEL picks one for A/B runs.
-int stack_kernel_choice() {                                   // 0 lattice, 1 stream, 2 windows
-    static int choice = -1;
-    if (choice < 0) {
-        const char* e = getenv("TORIC_STACK_KERNEL");
-        choice = (e && !strcmp(e, "lattice")) ? 0 : ((e && !strcmp(e, "stream")) ? 1 : 2);
-    }
-    return choice;
-}
-// sizes of the window index tables (window_write.hpp) for n lattices of size d: every qubit a hit at worst
-size_t widx_entries(int d, int64_t n) { const int64_t nq = 2 * d * d; return (size_t)((n * nq * nq) >> tq::WIN_LOG) + 2; }
-size_t pidx_entries(int d, int64_t n) { const int64_t nq = 2 * d * d; return (size_t)((n * nq * 3) >> tq::PWIN_LOG) + 2; }
-struct WinIndex {                                             // device tables: [0] written by the scan, [1] scratch of k_window_index
-    int32_t* widx[2] = {nullptr, nullptr};
-    int32_t* pidx[2] = {nullptr, nullptr};
-};
-int stream_cfg_choice() {
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("TORIC_STREAM_CFG"); cfg = e ? atoi(e) : 0; }
-    return cfg;
-}
-
+// The stack write (stream_write.hpp): SPLIT_MAX persistent workgroups, one per CU, each with its own contiguous
+// part of the stack.  Storer / producer waves per workgroup: the storers saturate a CU's store path with 2-4 waves
+// and the producers idle 80-90 % of the time for d >= 7 (profiles/r03_stack_write_ab.txt), but small lattices are
+// producer-bound (a d=3 lattice is 0.8 KB of output against a fixed set-up), so they get every wave that is left.
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, int* err, hipStream_t stream, int64_t first, int64_t count,
-                         const int32_t* split, const int32_t* widx, const int32_t* pidx, int num_cus) {
-    if (widx && stack_kernel_choice() == 2) {
-        // one persistent workgroup per CU (G = CUs * TORIC_WIN_WGS); windows are dealt round-robin over them
-        static int wgs = -1, cfg = -1;
-        if (wgs < 0) { const char* e = getenv("TORIC_WIN_WGS"); wgs = e ? atoi(e) : 1; wgs = wgs < 1 ? 1 : wgs; }
-        if (cfg < 0) cfg = stream_cfg_choice();
-        const unsigned G = (unsigned)(num_cus > 0 ? num_cus : 256) * (unsigned)wgs;
-#define WINK(NS, NP, K) hipLaunchKernelGGL((tq::k_persp_windows<D, OutT, NS, NP, K>), dim3(G), dim3(64 * (NS + 1 + NP)), 0, stream, \
-        vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, widx, pidx, (unsigned long long*)nullptr)
-        switch (cfg) {
-            case 1: WINK(8, 7, 32); break;
-            case 2: WINK(2, 5, 16); break;
-            case 3: WINK(4, 3, 16); break;
-            case 4: WINK(6, 9, 32); break;
-            default: WINK(4, 11, 32); break;
-        }
-#undef WINK
-        KCHECK();
-        return TQ_OK;
-    }
-    if (split && stack_kernel_choice() == 1) {
-        constexpr int RB = 14, RP = 12;                        // 64 KB bit ring, 16 KB position ring
-#define STREAM(NS, NP, CPW) hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP>), dim3(SPLIT_MAX), \
-        dim3(64 * (NS + 1 + NP)), 0, stream, vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split, \
-        (unsigned long long*)nullptr)
-        switch (stream_cfg_choice()) {
-            case 2: STREAM(2, 13, 8); break;
-            default: STREAM(4, 11, 8); break;
-        }
-#undef STREAM
-        KCHECK();
-        return TQ_OK;
-    }
-    // One wave per workgroup: the waves share nothing (no barrier, no common table), and a wave that has
-    // finished its lattice is replaced at once instead of waiting for the slowest of four (lattices differ
-    // by +-30 % in size): +1 % over 256-thread workgroups, 4 of 4 alternating runs (profiles/r02_wg_size_and_gate.txt).
-    constexpr int THREADS = 64;
-    constexpr int WAVES = THREADS / 64;
-    const int64_t blocks = (count + WAVES - 1) / WAVES;
-    hipLaunchKernelGGL((tq::k_persp_write<D, OutT, THREADS>), dim3((unsigned)blocks), dim3(THREADS), 0, stream, vp, n,
-                       offsets, (OutT*)out, pos, capacity, err, first, first + count);
+                         const int32_t* split) {
+    constexpr int NS = D <= 5 ? 2 : 4, NP = D <= 5 ? 13 : 11, CPW = 8;
+    constexpr int RB = 14, RP = 12;                            // 64 KB bit ring, 16 KB position ring
+    // a workgroup's part of the stack is addressed with 32-bit element offsets
+    if ((double)count * (2.0 * D * D) * (2.0 * D * D) / SPLIT_MAX > 2.0e9)
+        return fail(TQ_E_INVALID, "lattice range too large for one stack write (%lld lattices of d=%d)", (long long)count, D);
+    hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP>), dim3(SPLIT_MAX), dim3(64 * (NS + 1 + NP)), 0, stream,
+                       vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split, (unsigned long long*)nullptr);
     KCHECK();
     return TQ_OK;
 }
 
-// from_scan: the tables [0] (split, window index) came with the scan of these very offsets for this very lattice
-// range; otherwise they are computed here into the scratch tables [1] (k_split / k_window_index)
+// split == nullptr: the cut points did not come with the scan of these offsets (a lattice sub-range, or offsets from
+// elsewhere): every workgroup of the write finds its own two (find_cut)
 template <int D>
 int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                        int64_t capacity, int dtype, int* err, hipStream_t stream, int64_t first, int64_t count,
-                       bool from_scan, int32_t* split2, const WinIndex& wi, int num_cus) {
+                       const int32_t* split) {
     if (count == 0) return TQ_OK;
-    const int32_t* split = split2;                            // split2 = two tables of SPLIT_MAX + 2
-    const int32_t *widx = wi.widx[0], *pidx = wi.pidx[0];
-    if (!from_scan) {
-        if (stack_kernel_choice() == 1) {
-            hipLaunchKernelGGL(tq::k_split, dim3((SPLIT_MAX + 1 + 3) / 4), dim3(256), 0, stream, offsets, first, first + count,
-                               split2 + SPLIT_MAX + 2, SPLIT_LG);
-            split = split2 + SPLIT_MAX + 2;
-        } else if (stack_kernel_choice() == 2) {
-            hipLaunchKernelGGL(tq::k_window_index, grid1(count, 256), dim3(256), 0, stream, offsets, first, first + count, 2 * D * D,
-                               wi.widx[1], wi.pidx[1]);
-            widx = wi.widx[1]; pidx = wi.pidx[1];
-        }
-        KCHECK();
-    }
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, widx, pidx, num_cus);
-        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, widx, pidx, num_cus);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, widx, pidx, num_cus);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, widx, pidx, num_cus);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -270,9 +203,8 @@ struct tq_env {
     void* tblock;          // packed block of N slots: scratch of tq_transition_write
     const uint8_t* lut;
     int num_cus;
-    int32_t* split;        // cut points of the stream write: [0] table written by the scan, [1] scratch of k_split
-    const int64_t* split_for;   // offsets array the scan's tables belong to
-    WinIndex wi;           // window index of the windowed write
+    int32_t* split;        // cut points of the stack write, written by the scan (tq_persp_count)
+    const int64_t* split_for;   // the offsets array they belong to
 };
 
 namespace {
@@ -340,11 +272,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc((void**)&h->err, 4);
     alloc((void**)&h->mark, N * 4);
     alloc(&h->tblock, (size_t)tq::block_bytes(h->w, n_envs));
-    alloc((void**)&h->split, 2 * (SPLIT_MAX + 2) * sizeof(int32_t));
-    for (int t = 0; t < 2; ++t) {
-        alloc((void**)&h->wi.widx[t], widx_entries(d, n_envs) * sizeof(int32_t));
-        alloc((void**)&h->wi.pidx[t], pidx_entries(d, n_envs) * sizeof(int32_t));
-    }
+    alloc((void**)&h->split, (SPLIT_MAX + 2) * sizeof(int32_t));
     h->reset_epoch = 0;
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
@@ -365,7 +293,6 @@ int tq_destroy(tq_env* h) {
     DeviceGuard guard;
     (void)guard.enter_device(h->device);
     (void)hipFree(h->mark); (void)hipFree(h->tblock); (void)hipFree(h->split);
-    for (int t = 0; t < 2; ++t) { (void)hipFree(h->wi.widx[t]); (void)hipFree(h->wi.pidx[t]); }
     (void)hipFree(h->planes); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
     (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->err);
     delete h;
@@ -537,8 +464,7 @@ int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream_) 
     if (!offsets) return fail(TQ_E_INVALID, "offsets is NULL");
     REQUIRE_ALIGNED16(offsets, "offsets");
     REQUIRE_ALIGNED16(counts, "counts");
-    if (int rc = launch_scan(h->counts, h->partial, h->partial_valid, offsets, counts, h->n, stream, h->split, h->wi.widx[0],
-                             h->wi.pidx[0], 2 * h->d * h->d)) return rc;
+    if (int rc = launch_scan(h->counts, h->partial, h->partial_valid, offsets, counts, h->n, stream, h->split)) return rc;
     h->partial_valid = true;
     h->split_for = offsets;
     return TQ_OK;
@@ -553,11 +479,11 @@ int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count
     REQUIRE_ALIGNED16(out, "out");
     REQUIRE_ALIGNED16(positions, "positions");
     const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
-    // the tables of the whole batch came with the scan of these very offsets; a lattice sub-range, or offsets from
-    // elsewhere, get theirs from k_window_index
-    const bool from_scan = first == 0 && count == h->n && offsets == h->split_for;
+    // the cut points of the whole batch came with the scan of these very offsets; for a lattice sub-range, or offsets
+    // from elsewhere, the workgroups find theirs themselves
+    const int32_t* split = (first == 0 && count == h->n && offsets == h->split_for) ? h->split : nullptr;
 #define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream, first, count, \
-        from_scan, h->split, h->wi, h->num_cus)) return rc
+        split)) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;
@@ -574,8 +500,7 @@ static size_t states_scratch_bytes(int d, int64_t n) {
     const size_t w = (size_t)(d * d + 63) / 64;
     const size_t cnt_bytes = (((size_t)n * 4 + 32 + 15) & ~(size_t)15);
     const size_t part_bytes = (((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8;
-    const size_t idx_bytes = 2 * (((widx_entries(d, n) + pidx_entries(d, n)) * 4 + 15) & ~(size_t)15);
-    return 2 * w * (size_t)n * 8 + cnt_bytes + ((part_bytes + 15) & ~(size_t)15) + idx_bytes;
+    return 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes;
 }
 
 // set-up call: allocates (and synchronises); the tq_states_persp_* calls themselves never allocate
@@ -600,7 +525,7 @@ int tq_states_reserve(int d, int n_max) {
     return TQ_OK;
 }
 
-static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int** err, WinIndex* wi) {
+static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts, int64_t** partial, int** err) {
     DeviceCtx& c = g_ctx[dev];
     std::lock_guard<std::mutex> lock(c.mu);
     const size_t w = (size_t)(d * d + 63) / 64;
@@ -610,13 +535,6 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
     *vp = (uint64_t*)c.ws;
     *counts = (int32_t*)((char*)c.ws + 2 * w * (size_t)n * 8);
     *partial = (int64_t*)((char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes);
-    const size_t part_bytes = (((((size_t)n + tq::PART_BLOCK - 1) / tq::PART_BLOCK) * 8) + 15) & ~(size_t)15;
-    char* ip = (char*)c.ws + 2 * w * (size_t)n * 8 + cnt_bytes + part_bytes;
-    const size_t one = ((widx_entries(d, n) + pidx_entries(d, n)) * 4 + 15) & ~(size_t)15;
-    for (int t = 0; t < 2; ++t) {
-        wi->widx[t] = (int32_t*)(ip + t * one);
-        wi->pidx[t] = wi->widx[t] + widx_entries(d, n);
-    }
     *err = c.err;
     return TQ_OK;
 }
@@ -631,13 +549,13 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut_unused;
     if (int rc = get_lut(dev, d, stream, &lut_unused)) return rc;
-    uint64_t* vp; int32_t* cnt; int64_t* part; int* err; WinIndex wi;
-    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err, &wi)) return rc;
+    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
 #define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, cnt, (int64_t)n)
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-    if (int rc = launch_scan(cnt, part, false, offsets, counts, n, stream, g_ctx[dev].split, wi.widx[0], wi.pidx[0], 2 * d * d)) return rc;
+    if (int rc = launch_scan(cnt, part, false, offsets, counts, n, stream, g_ctx[dev].split)) return rc;
     g_ctx[dev].split_for = offsets;
     g_ctx[dev].split_n = n; g_ctx[dev].split_d = d;
     return TQ_OK;
@@ -654,17 +572,15 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     if (int rc = current_device(&dev)) return rc;
     const uint8_t* lut;
     if (int rc = get_lut(dev, d, stream, &lut)) return rc;
-    uint64_t* vp; int32_t* cnt; int64_t* part; int* err; WinIndex wi;
-    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err, &wi)) return rc;
+    uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
+    if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
 #define CALL(D) hipLaunchKernelGGL(tq::k_pack_states<D>, grid1(n, 256), dim3(256), 0, stream, states, vp, (int32_t*)nullptr, (int64_t)n)
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-    // tables of the last tq_states_persp_count, if it scanned these offsets for the same batch shape (the scratch
-    // layout depends on d and n)
-    const bool from_scan = offsets == g_ctx[dev].split_for && g_ctx[dev].split_n == n && g_ctx[dev].split_d == d;
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, err, stream, 0, n, from_scan, \
-        g_ctx[dev].split, wi, g_ctx[dev].num_cus)) return rc
+    // cut points of the last tq_states_persp_count, if it scanned these very offsets for a batch of this shape
+    const int32_t* split = (offsets == g_ctx[dev].split_for && g_ctx[dev].split_n == n && g_ctx[dev].split_d == d) ? g_ctx[dev].split : nullptr;
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, err, stream, 0, n, split)) return rc
     DISPATCH_D(d, CALL)
 #undef CALL
     return TQ_OK;

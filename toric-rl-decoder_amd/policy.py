@@ -41,11 +41,22 @@ class NN_11(nn.Module):
         return self.linear1(x.flatten(1))
 
 
-def _forward_chunked(model, persp, chunk):
+def _forward_chunked(model, persp, chunk, pad_to=1024):
+    """model(persp) in chunks of `chunk` rows.  The last, ragged chunk is zero-padded to a multiple of `pad_to` rows
+    (and its Q rows cut off again): the number of perspectives changes every step, and every new batch size is a new
+    problem for MIOpen's solver search -- a handful of shapes instead of thousands."""
     outs = []
+    n = persp.shape[0]
     with torch.no_grad():
-        for i in range(0, persp.shape[0], chunk):
-            outs.append(model(persp[i:i + chunk]).float())
+        for i in range(0, n, chunk):
+            x = persp[i:i + chunk]
+            r = x.shape[0]
+            if r < chunk and pad_to > 1 and r % pad_to:
+                xp = torch.zeros((min(chunk, (r + pad_to - 1) // pad_to * pad_to),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                xp[:r] = x
+                outs.append(model(xp)[:r].float())
+            else:
+                outs.append(model(x).float())
     if not outs:
         return torch.zeros((0, 3), dtype=torch.float32, device=persp.device)
     return torch.cat(outs, dim=0)

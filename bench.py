@@ -80,6 +80,10 @@ def parse(argv=None):
                          "its own PCIe link (0 = auto: 2 from 8 ranks on, where one Gen5 x16 link no longer carries "
                          "the ~63 GB/s of packed records; 1 below)")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
+    ap.add_argument("--stack-candidates", type=int, default=4,
+                    help="stack buffers to allocate at set-up; the one the write kernel is fastest on is kept, the others are "
+                         "freed (where a buffer lies in HBM changes the write rate by up to 20 %% on this part: "
+                         "profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--nn-steps", type=int, default=3,
                     help="N=1: timed steps of the NN_11-in-the-loop leg (configs[2] as written); 0 = skip")
@@ -182,7 +186,7 @@ class Shard:
     """One sub-shard of this GPU's lattices with its stream and its caller-owned output buffers."""
 
 
-def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False):
+def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False, candidates=1):
     """The same pass over a batch of `n` lattices on the current stream, no collective: burn-in, `warm` untimed
     and `steps` timed steps.  -> (seconds, perspectives in the timed steps, per-step stack-write milliseconds
     from HIP events or None).  Used at N=1 for the extra legs of the line: one GPU on the per-GPU shape of the
@@ -201,6 +205,10 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
         if idx.numel():
             envs.resetTerminalEnvs(idx)
         envs.actorStep(None, want_actions=False)
+    if candidates > 1 and chunks == 1:                               # placement probe, as in the main loop
+        del stack
+        torch.cuda.empty_cache()
+        stack, _ = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions)
 
     def step(t):
         off = offs[t][:n + 1]
@@ -467,6 +475,17 @@ def main():
                     sh.envs.actorStep(None, want_actions=False)
         barrier()
 
+    # ---- placement probe (set-up, untimed): the same stack write on every candidate buffer, keep the fastest
+    probe = None
+    if args.stack_candidates > 1 and S == 1 and CH == 1 and not args.graph:
+        sh0 = shards[0]
+        del sh0.stack
+        torch.cuda.empty_cache()
+        sh0.stack, probe = sh0.envs.pickStackBuffer(args.stack_candidates, dtype=tdtype, capacity=cap, positions=sh0.positions)
+        probe["note"] = ("set-up, untimed (EnvSet.pickStackBuffer): 3 stack writes timed on each candidate buffer -- plain torch.empty "
+                         "allocations of the same size, one after the other -- the fastest kept, the others freed; candidate 0 is the "
+                         "allocation a caller gets by default")
+
     graph = None
     if args.graph:
         # the capture stream is torch's current stream inside torch.cuda.graph(); every ABI call
@@ -542,7 +561,7 @@ def main():
     if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore" and not args.no_shard_leg:
         k2, w2 = max(8, min(K, 40)), 8
         print("[bench] configs[4] shard leg (131072 lattices on this GPU) ...", file=sys.stderr, flush=True)
-        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2)
+        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
                      "perspectives_per_sec": P2 / dt2,
                      "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
@@ -559,7 +578,8 @@ def main():
                   "steps": k3, "warmup": w3}
         for name, ch in (("one_shot", 1), ("chunks_4", 4)):
             print("[bench] configs[3] leg (65536 lattices, d=9, p=0.15), %s ..." % name, file=sys.stderr, flush=True)
-            dt3, P3, ev3 = time_plain_loop(T, torch, env3, n3, d3, args.seed, 0, tdtype, flush, device, k3, w3, chunks=ch, events=True)
+            dt3, P3, ev3 = time_plain_loop(T, torch, env3, n3, d3, args.seed, 0, tdtype, flush, device, k3, w3, chunks=ch, events=True,
+                                           candidates=args.stack_candidates)
             alg3 = P3 / k3 * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
             c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
                             "perspectives_per_sec": P3 / dt3, "perspectives_per_lattice": P3 / (k3 * n3),
@@ -642,6 +662,8 @@ def main():
             "perspectives_per_sec": float(p_sum.item()) / elapsed,
             "perspectives_per_lattice": float(p_sum.item()) / total_steps,
         }
+        if probe is not None:
+            res["stack_buffer_probe"] = probe
         if hbm_ring is not None:
             res["hbm_ring"] = hbm_ring
         if shard_leg is not None:

@@ -41,6 +41,51 @@ __global__ void k_diff(const uint32_t* a, const uint32_t* b, int64_t n, unsigned
     if (c) atomicAdd(bad, c);
 }
 
+// One virtual range backed by physical chunks of `chunk` bytes mapped in a SHUFFLED order (HIP virtual memory API):
+// consecutive chunks of the buffer lie in unrelated places of the HBM.
+static float* alloc_shuffled(size_t bytes, size_t chunk, unsigned seed) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gran = 0;
+    CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    void* va = nullptr;
+    CK(hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0));
+    std::vector<size_t> perm(n);
+    for (size_t i = 0; i < n; ++i) perm[i] = i;
+    std::mt19937 rng(seed);
+    if (seed) std::shuffle(perm.begin(), perm.end(), rng);
+    for (size_t i = 0; i < n; ++i) {
+        hipMemGenericAllocationHandle_t hnd;
+        CK(hipMemCreate(&hnd, chunk, &prop, 0));
+        CK(hipMemMap((char*)va + perm[i] * chunk, chunk, 0, hnd, 0));
+        CK(hipMemRelease(hnd));
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(va, n * chunk, &acc, 1));
+    return (float*)va;
+}
+
+// pure store pattern: G workgroups x NS waves; windows of WIN bytes dealt round-robin over the workgroups, inside a
+// workgroup over its waves; a wave streams its window with 16 B per lane stores
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void k_front(char* __restrict__ out, int64_t bytes, int win) {
+    const tq::u32x4 v = {0x3F800000u, 0u, 0x3F800000u, 0u};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t nwin = bytes / win;
+    for (int64_t i = wave;; i += NS) {
+        const int64_t w = blockIdx.x + i * (int64_t)gridDim.x;
+        if (w >= nwin) break;
+        char* p = out + w * win + lane * 16;
+        for (int o = 0; o < win; o += 1024) *reinterpret_cast<tq::u32x4*>(p + o) = v;
+    }
+}
+
 struct Timer {
     hipEvent_t e0, e1;
     Timer() { CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); }
@@ -171,9 +216,21 @@ int run(int64_t N, double q) {
     auto timeit = [&](auto k) { float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(k); if (r) a += x; } return bytes / (a / 5) / 1e6; };
     constexpr int NSP = D <= 5 ? 2 : 4, NPP = D <= 5 ? 13 : 11;       // the library's configuration (toricenv.hip)
     std::vector<float*> bufs; std::vector<double> rate;
-    for (int b = 0; b < 6; ++b) { float* x; CK(hipMalloc(&x, (size_t)P * NQ * 4 + 4096 + (size_t)b * (3u << 20))); bufs.push_back(x); }
-    printf("six output buffers, the same launches on each (GB/s of algorithmic bytes; memset: stack bytes only):\n");
-    for (int b = 0; b < 6; ++b) {
+    const char* kind[8] = {"hipMalloc", "hipMalloc", "contiguous flag", "VMM 2 MiB in order", "VMM 2 MiB shuffled", "VMM 2 MiB shuffled", "VMM 32 MiB shuffled", "VMM 256 KiB? shuffled"};
+    for (int b = 0; b < 8; ++b) {
+        float* x;
+        const size_t sz = (size_t)P * NQ * 4 + 4096 + (size_t)b * (3u << 20);
+        if (b < 2) CK(hipMalloc(&x, sz));
+        else if (b == 2) CK(hipExtMallocWithFlags((void**)&x, sz, hipDeviceMallocContiguous));
+        else if (b == 3) x = alloc_shuffled(sz, 2u << 20, 0);
+        else if (b == 4) x = alloc_shuffled(sz, 2u << 20, 11);
+        else if (b == 5) x = alloc_shuffled(sz, 2u << 20, 12);
+        else if (b == 6) x = alloc_shuffled(sz, 32u << 20, 13);
+        else x = alloc_shuffled(sz, 256u << 10, 14);
+        bufs.push_back(x);
+    }
+    printf("output buffers of different physical make-up, the same launches on each (GB/s of algorithmic bytes; memset: stack bytes only):\n");
+    for (int b = 0; b < 8; ++b) {
         float* ob = bufs[b];
         auto ks = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NSP, NPP, 8, 14, 12>), dim3(256), dim3(64 * (NSP + 1 + NPP)), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, (unsigned long long*)nullptr); };
         auto kl = [&] { hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N); };
@@ -186,8 +243,38 @@ int run(int64_t N, double q) {
         int e; CK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));
         const double rs = timeit(ks), rl = timeit(kl), rm = timeit(km) * ((double)P * NQ * 4) / bytes;
         rate.push_back(rs);
-        printf("  buffer %d: stream %6.0f   one wave per lattice %6.0f   hipMemsetAsync %6.0f   (stream vs lattice: %llu differing dwords, latch %d)\n",
-               b, rs, rl, rm, nb, e);
+        printf("  buffer %d %-22s: stream %6.0f   one wave per lattice %6.0f   hipMemsetAsync %6.0f   (stream vs lattice: %llu differing dwords, latch %d)\n",
+               b, kind[b], rs, rl, rm, nb, e);
+    }
+    {   // pure store patterns on every buffer: windows of WIN bytes round-robin over 256 workgroups x NS waves
+        printf("pure store pattern (constant data), GB/s of stack bytes: windows round-robin over 256 workgroups x NS waves\n");
+        const int64_t sb = (int64_t)P * NQ * 4 / (1 << 20) * (1 << 20);
+        for (int b = 0; b < 7; ++b) {
+            char* ob = (char*)bufs[b];
+            printf("  buffer %d %-20s:", b, kind[b]);
+            for (int win : {1024, 4096, 8192, 32768}) {
+                auto k4 = [&] { hipLaunchKernelGGL(k_front<4>, dim3(256), dim3(256), 0, 0, ob, sb, win); };
+                auto k16 = [&] { hipLaunchKernelGGL(k_front<16>, dim3(256), dim3(1024), 0, 0, ob, sb, win); };
+                float a = 0, c = 0;
+                for (int r = 0; r < 6; ++r) { float x = t.run(k4), y = t.run(k16); if (r) { a += x; c += y; } }
+                printf("  %2dK: NS=4 %5.0f NS=16 %5.0f", win / 1024, sb / (a / 5) / 1e6, sb / (c / 5) / 1e6);
+            }
+            printf("\n");
+        }
+    }
+    {   // does the rate on a physically contiguous buffer depend on the spacing of the 256 streams (= range size / 256)?
+        float* ob = bufs[2];
+        std::vector<int64_t> ho((size_t)N + 1);
+        CK(hipMemcpy(ho.data(), off, 8 * (N + 1), hipMemcpyDeviceToHost));
+        printf("contiguous buffer, lattice sub-ranges [0, f*N): stream spacing vs rate\n");
+        for (double f : {1.0, 0.97, 0.94, 0.9, 0.85, 0.8, 0.75, 0.7, 0.6, 0.5}) {
+            const int64_t e1 = (int64_t)(N * f);
+            const int64_t Pr = ho[e1];
+            const double by = (double)Pr * (NQ * 4 + 12) + (double)e1 * NQ;
+            auto ks = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NSP, NPP, 8, 14, 12>), dim3(256), dim3(64 * (NSP + 1 + NPP)), 0, 0, vp, N, off, ob, p2, Pr, err, (int64_t)0, e1, (const int32_t*)nullptr, (unsigned long long*)nullptr); };
+            float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(ks); if (r) a += x; }
+            printf("    f=%.2f  spacing %8.3f MB  %6.0f GB/s\n", f, (double)Pr * NQ * 4 / 256 / 1e6, by / (a / 5) / 1e6);
+        }
     }
     const int fast = (int)(std::max_element(rate.begin(), rate.end()) - rate.begin()), slow = (int)(std::min_element(rate.begin(), rate.end()) - rate.begin());
     for (int which : {fast, slow}) {

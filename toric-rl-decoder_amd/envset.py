@@ -377,6 +377,38 @@ class EnvSet:
                        _DTYPES[out.dtype])
         self._positions = positions
 
+    def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=3):
+        """Set-up helper: allocate ``candidates`` stack buffers (``capacity`` perspectives each, default the worst
+        case no_envs * 2*d*d), time the stack write of the CURRENT lattices on each of them and keep the fastest.
+        Where a buffer lies in HBM changes the rate of ANY write stream into it by up to 20 % on MI355X (a plain fill
+        included; profiles/r03_stack_write_ab.txt), and a caller writes the same buffer every step, so the choice is
+        worth a few launches at set-up.  -> (stack tensor (capacity,2,d,d), report dict with the ms of every
+        candidate).  Synchronises; never call it in the step loop."""
+        d, nq = self.size, 2 * self.size * self.size
+        cap = self.no_envs * nq if capacity is None else int(capacity)
+        if positions is None:
+            positions = torch.empty((cap, 3), dtype=torch.int32, device=self.device)
+        _, off = self.perspectiveCounts()
+        off = off.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms, keep = [], []          # every candidate stays allocated until the choice is made: distinct placements
+        for _ in range(max(1, int(candidates))):
+            c = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
+            keep.append(c)
+            t = []
+            for r in range(int(launches) + 1):
+                e0.record()
+                self.writePerspectives(c, positions, off)
+                e1.record()
+                e1.synchronize()
+                t.append(e0.elapsed_time(e1))
+            ms.append(float(np.mean(t[1:])))
+        self.check()
+        best = keep[int(np.argmin(ms))]
+        del keep, c
+        torch.cuda.empty_cache()
+        return best, {"candidates": len(ms), "write_ms": ms, "chosen": int(np.argmin(ms))}
+
     def generatePerspective(self, states=None, dtype=torch.float32):
         """generatePerspectiveBatch + concatenate (numba/util_actor.py:33-39,56-67) for the current
         states, or for an explicit ``states`` array (n,2,d,d) like the reference's function

@@ -133,9 +133,9 @@ def learner_and_priority_vectors(d, rng):
 def main():
     rng = np.random.default_rng(20200318)
     report = []
-    for d in (3, 5, 7, 9, 11):        # 11 last: the draws of the d <= 9 files are unchanged
+    for d in (3, 5, 7, 9, 11, 13, 15):        # new sizes last: the draws of the earlier files are unchanged
         gs = int(d / 2)
-        k = {3: 40, 5: 30, 7: 24, 9: 16, 11: 8}[d]
+        k = {3: 40, 5: 30, 7: 24, 9: 16, 11: 8, 13: 6, 15: 5}[d]
         states = random_states(rng, d, k)
         n = states.shape[0]
 

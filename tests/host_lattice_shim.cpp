@@ -126,6 +126,7 @@ static void t_step(int n, uint8_t* q, const int32_t* act, uint8_t* st, int32_t* 
         case 9: CALL(9); break;            \
         case 11: CALL(11); break;          \
         case 13: CALL(13); break;          \
+        case 15: CALL(15); break;          \
         default: return -1;                \
     }                                      \
     return 0;

@@ -13,8 +13,8 @@ from oracle import toric_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-SIZES = (3, 5, 7, 9, 11)
-P_OF = {3: 0.1, 5: 0.1, 7: 0.1, 9: 0.15, 11: 0.1}
+SIZES = (3, 5, 7, 9, 11, 13, 15)
+P_OF = {3: 0.1, 5: 0.1, 7: 0.1, 9: 0.15, 11: 0.1, 13: 0.1, 15: 0.08}
 
 
 @pytest.fixture(scope="module")
@@ -112,7 +112,7 @@ def test_config2_4096_envs_d5_bit_exact(T):
 
 
 # ------------------------------------------------------------------ reference golden vectors on the GPU
-@pytest.mark.parametrize("d", (3, 5, 7, 9, 11))
+@pytest.mark.parametrize("d", SIZES)
 def test_golden_reference_vectors(T, golden_dir, d):
     g = np.load(os.path.join(golden_dir, f"reference_d{d}.npz"), allow_pickle=False)
     per, pos, cnt = T.generatePerspectiveBatch(d // 2, d, g["states"], dtype=torch.float32)
@@ -275,7 +275,7 @@ def test_bad_actions_and_capacity_are_reported(T):
 
 
 # ------------------------------------------------------------------ fused actor step
-@pytest.mark.parametrize("d,strategy", [(3, "random"), (5, "linear"), (7, "fixed"), (9, "random")])
+@pytest.mark.parametrize("d,strategy", [(3, "random"), (5, "linear"), (7, "fixed"), (9, "random"), (13, "linear"), (15, "random")])
 def test_fused_actor_step_matches_oracle_loop(T, d, strategy):
     """tq_actor_step (step -> transition -> scheduled auto-reset -> counts) against the same loop
     spelled out with oracle calls in the order of Actor_mp.py:104-185."""

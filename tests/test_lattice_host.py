@@ -12,7 +12,7 @@ import pytest
 from oracle import toric_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIZES = (3, 5, 7, 9, 11, 13)
+SIZES = (3, 5, 7, 9, 11, 13, 15)
 
 
 @pytest.fixture(scope="module")

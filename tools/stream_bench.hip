@@ -214,7 +214,7 @@ int run(int64_t N, double q) {
     unsigned long long* bad; CK(hipMalloc(&bad, 8));
     Timer t;
     auto timeit = [&](auto k) { float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(k); if (r) a += x; } return bytes / (a / 5) / 1e6; };
-    constexpr int NSP = D <= 5 ? 2 : 4, NPP = D <= 5 ? 13 : 11;       // the library's configuration (toricenv.hip)
+    constexpr int NSP = D <= 5 ? 2 : 4, NPP = D <= 5 ? 13 : (D >= 13 ? 7 : 11);       // the library's configuration (toricenv.hip)
     std::vector<float*> bufs; std::vector<double> rate;
     const char* kind[8] = {"hipMalloc", "hipMalloc", "contiguous flag", "VMM 2 MiB in order", "VMM 2 MiB shuffled", "VMM 2 MiB shuffled", "VMM 32 MiB shuffled", "VMM 256 KiB? shuffled"};
     for (int b = 0; b < 8; ++b) {

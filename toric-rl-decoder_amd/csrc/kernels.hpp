@@ -722,17 +722,17 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// (hit, cell) -> source cell table, u8[NQ][NQ] (NQ <= 255 for d <= 11): filled once per handle; used by
-// k_states_transition (the stack write needs no table any more).
+// (hit, cell) -> source cell table, u16[NQ][NQ] (NQ = 450 at d = 15): filled once per (device, size); used by
+// k_states_transition (the stack write needs no table).
 template <int D>
-__global__ void k_build_lut(uint8_t* __restrict__ lut) {
+__global__ void k_build_lut(uint16_t* __restrict__ lut) {
     using L = Lat<D>;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= L::NQ * L::NQ) return;
     const int hit = t / L::NQ, cell = t - hit * L::NQ;
     const int layer = hit >= L::DD, hrem = hit - layer * L::DD, i = hrem / D, j = hrem - i * D;
     const int c = cell >= L::DD, crem = cell - c * L::DD, r = crem / D, s = crem - r * D;
-    lut[t] = (uint8_t)L::persp_src(layer, i, j, c, r, s);
+    lut[t] = (uint16_t)L::persp_src(layer, i, j, c, r, s);
 }
 
 // `VEC` stream bits -> the four dwords of one 16-byte lane store
@@ -762,7 +762,7 @@ template <int D>
 __global__ __launch_bounds__(256) void k_states_transition(const uint8_t* __restrict__ st, const uint8_t* __restrict__ nst,
                                                            const int32_t* __restrict__ actions, uint8_t* __restrict__ persp,
                                                            uint8_t* __restrict__ next_persp, int32_t* __restrict__ actions_out,
-                                                           const uint8_t* __restrict__ lut, int64_t n, int* __restrict__ err) {
+                                                           const uint16_t* __restrict__ lut, int64_t n, int* __restrict__ err) {
     using L = Lat<D>;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * L::NQ) return;

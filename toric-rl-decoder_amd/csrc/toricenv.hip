@@ -37,7 +37,7 @@ int fail(int code, const char* fmt, ...) {
 #define KCHECK() HIPCHECK(hipGetLastError())
 
 constexpr int MAX_DEVICES = 16;
-constexpr int kSizes[] = {3, 5, 7, 9, 11};
+constexpr int kSizes[] = {3, 5, 7, 9, 11, 13, 15};
 
 bool size_ok(int d) {
     for (int s : kSizes) if (s == d) return true;
@@ -48,7 +48,7 @@ int size_slot(int d) { return (d - 3) / 2; }
 // per-device caches shared by handles and the stateless entry points
 struct DeviceCtx {
     std::mutex mu;
-    uint8_t* lut[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint16_t* lut[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int* err = nullptr;             // error latch of the stateless entry points (tq_states_check)
     void* ws = nullptr;             // scratch of the tq_states_persp_* entry points (tq_states_reserve)
     size_t ws_bytes = 0;
@@ -89,7 +89,9 @@ int decode_latch(int flag) {
         case 7: CALL(7); break;      \
         case 9: CALL(9); break;      \
         case 11: CALL(11); break;    \
-        default: return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d); \
+        case 13: CALL(13); break;    \
+        case 15: CALL(15); break;    \
+        default: return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d); \
     }
 
 int current_device(int* dev) {
@@ -98,14 +100,14 @@ int current_device(int* dev) {
     return TQ_OK;
 }
 
-int get_lut(int dev, int d, hipStream_t stream, const uint8_t** out) {
+int get_lut(int dev, int d, hipStream_t stream, const uint16_t** out) {
     DeviceCtx& c = g_ctx[dev];
     std::lock_guard<std::mutex> lock(c.mu);
     const int slot = size_slot(d);
     if (!c.lut[slot]) {
         const int nq = 2 * d * d;
-        const size_t bytes = ((size_t)nq * nq + 15) & ~(size_t)15;
-        uint8_t* p = nullptr;
+        const size_t bytes = (2 * (size_t)nq * nq + 15) & ~(size_t)15;
+        uint16_t* p = nullptr;
         HIPCHECK(hipMalloc(&p, bytes));
         HIPCHECK(hipMemsetAsync(p, 0, bytes, stream));
 #define CALL(D) hipLaunchKernelGGL(tq::k_build_lut<D>, grid1((int64_t)nq * nq, 256), dim3(256), 0, stream, p)
@@ -152,7 +154,7 @@ template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, int* err, hipStream_t stream, int64_t first, int64_t count,
                          const int32_t* split) {
-    constexpr int NS = D <= 5 ? 2 : 4, NP = D <= 5 ? 13 : 11, CPW = 8;
+    constexpr int NS = D <= 5 ? 2 : 4, NP = D <= 5 ? 13 : (D >= 13 ? 7 : 11), CPW = 8;
     constexpr int RB = 14, RP = 12;                            // 64 KB bit ring, 16 KB position ring
     // a workgroup's part of the stack is addressed with 32-bit element offsets
     if ((double)count * (2.0 * D * D) * (2.0 * D * D) / SPLIT_MAX > 2.0e9)
@@ -201,7 +203,7 @@ struct tq_env {
     uint32_t* mark;        // [N] epoch of the last indexed reset that touched the lattice (duplicate detection)
     uint32_t reset_epoch;
     void* tblock;          // packed block of N slots: scratch of tq_transition_write
-    const uint8_t* lut;
+    const uint16_t* lut;
     int num_cus;
     int32_t* split;        // cut points of the stack write, written by the scan (tq_persp_count)
     const int64_t* split_for;   // the offsets array they belong to
@@ -243,7 +245,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     if (!out) return fail(TQ_E_INVALID, "out is NULL");
     *out = nullptr;
     if (n_envs <= 0) return fail(TQ_E_INVALID, "n_envs must be > 0 (got %d)", n_envs);
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
     if (first_env_id < 0 || first_env_id + n_envs > 0xFFFFFFFFll)
         return fail(TQ_E_INVALID, "global env ids must fit in 32 bits");
     int ndev = 0;
@@ -505,11 +507,11 @@ static size_t states_scratch_bytes(int d, int64_t n) {
 
 // set-up call: allocates (and synchronises); the tq_states_persp_* calls themselves never allocate
 int tq_states_reserve(int d, int n_max) {
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
     if (n_max <= 0) return fail(TQ_E_INVALID, "n_max must be > 0");
     int dev;
     if (int rc = current_device(&dev)) return rc;
-    const uint8_t* lut_unused;
+    const uint16_t* lut_unused;
     if (int rc = get_lut(dev, d, nullptr, &lut_unused)) return rc;
     DeviceCtx& c = g_ctx[dev];
     std::lock_guard<std::mutex> lock(c.mu);
@@ -541,13 +543,13 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
 
 int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, int64_t* offsets, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
     if (n <= 0 || !states || !offsets) return fail(TQ_E_INVALID, "bad n / states / offsets");
     REQUIRE_ALIGNED16(offsets, "offsets");
     REQUIRE_ALIGNED16(counts, "counts");
     int dev;
     if (int rc = current_device(&dev)) return rc;
-    const uint8_t* lut_unused;
+    const uint16_t* lut_unused;
     if (int rc = get_lut(dev, d, stream, &lut_unused)) return rc;
     uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
     if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
@@ -564,13 +566,13 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
 int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* offsets, void* out,
                           int32_t* positions, int64_t capacity, int dtype, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
     if (n <= 0 || !states || !offsets || !out || capacity < 0) return fail(TQ_E_INVALID, "bad arguments");
     REQUIRE_ALIGNED16(out, "out");
     REQUIRE_ALIGNED16(positions, "positions");
     int dev;
     if (int rc = current_device(&dev)) return rc;
-    const uint8_t* lut;
+    const uint16_t* lut;
     if (int rc = get_lut(dev, d, stream, &lut)) return rc;
     uint64_t* vp; int32_t* cnt; int64_t* part; int* err;
     if (int rc = states_scratch(dev, d, n, &vp, &cnt, &part, &err)) return rc;
@@ -589,13 +591,13 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
 int tq_states_transition(int d, int n, const uint8_t* states, const uint8_t* next_states, const int32_t* actions,
                          uint8_t* persp, uint8_t* next_persp, int32_t* actions_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
     if (n <= 0 || !actions || (persp && !states) || (next_persp && !next_states)) return fail(TQ_E_INVALID, "bad arguments");
     REQUIRE_ALIGNED16(actions, "actions");
     REQUIRE_ALIGNED16(actions_out, "actions_out");
     int dev;
     if (int rc = current_device(&dev)) return rc;
-    const uint8_t* lut;
+    const uint16_t* lut;
     if (int rc = get_lut(dev, d, stream, &lut)) return rc;
     int* err = g_ctx[dev].err;
     const int64_t total = (int64_t)n * 2 * d * d;
@@ -685,7 +687,7 @@ int tq_transition_write(tq_env* h, const int32_t* actions, uint8_t* persp, uint8
 int tq_block_priorities(int d, void* block, int64_t cap, int n_envs, int n_steps, const float* q_values,
                         double discount, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
     if (!block || n_envs <= 0 || n_steps <= 0 || (int64_t)n_envs * n_steps > cap)
         return fail(TQ_E_INVALID, "bad block / n_envs / n_steps (n_envs * n_steps must be <= cap)");
     tq::BlockView b = tq::block_view(block, (d * d + 63) / 64, cap);
@@ -699,7 +701,7 @@ int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, i
                          uint8_t* next_persp, int32_t* actions, float* rewards, uint8_t* terminals, float* priorities,
                          void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..11)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
     if (!block || first < 0 || count < 0 || first + count > cap) return fail(TQ_E_INVALID, "bad block / slot range");
     if (count == 0) return TQ_OK;
     REQUIRE_ALIGNED16(actions, "actions");

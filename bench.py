@@ -80,10 +80,15 @@ def parse(argv=None):
                          "its own PCIe link (0 = auto: 2 from 8 ranks on, where one Gen5 x16 link no longer carries "
                          "the ~63 GB/s of packed records; 1 below)")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
-    ap.add_argument("--stack-candidates", type=int, default=4,
+    ap.add_argument("--stack-candidates", type=int, default=8,
                     help="stack buffers to allocate at set-up; the one the write kernel is fastest on is kept, the others are "
                          "freed (where a buffer lies in HBM changes the write rate by up to 20 %% on this part: "
-                         "profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")
+                         "profiles/r03_stack_write_ab.txt; the probe stops at the first candidate that is 14 %% faster than the "
+                         "first).  1 = take the first allocation as it comes")
+    ap.add_argument("--stack-kinds", default="torch,chunked",
+                    help="where candidate k comes from, cyclically: torch = torch.empty, chunked = T.alloc_stack (2 MiB physical "
+                         "chunks, tq_stack_alloc).  Profile runs use --stack-candidates 1 --stack-kinds chunked so that every "
+                         "launch of the process writes the same buffer")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--nn-steps", type=int, default=3,
                     help="N=1: timed steps of the NN_11-in-the-loop leg (configs[2] as written); 0 = skip")
@@ -186,7 +191,8 @@ class Shard:
     """One sub-shard of this GPU's lattices with its stream and its caller-owned output buffers."""
 
 
-def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False, candidates=1):
+def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False, candidates=1,
+                    kinds=("torch", "chunked")):
     """The same pass over a batch of `n` lattices on the current stream, no collective: burn-in, `warm` untimed
     and `steps` timed steps.  -> (seconds, perspectives in the timed steps, per-step stack-write milliseconds
     from HIP events or None).  Used at N=1 for the extra legs of the line: one GPU on the per-GPU shape of the
@@ -208,7 +214,7 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
     if candidates > 1 and chunks == 1:                               # placement probe, as in the main loop
         del stack
         torch.cuda.empty_cache()
-        stack, _ = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions)
+        stack, _ = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions, kinds=kinds)
 
     def step(t):
         off = offs[t][:n + 1]
@@ -477,14 +483,15 @@ def main():
 
     # ---- placement probe (set-up, untimed): the same stack write on every candidate buffer, keep the fastest
     probe = None
-    if args.stack_candidates > 1 and S == 1 and CH == 1 and not args.graph:
+    kinds = tuple(k for k in args.stack_kinds.split(",") if k in ("torch", "chunked")) or ("torch",)
+    if (args.stack_candidates > 1 or kinds[0] != "torch") and S == 1 and CH == 1 and not args.graph:
         sh0 = shards[0]
         del sh0.stack
         torch.cuda.empty_cache()
-        sh0.stack, probe = sh0.envs.pickStackBuffer(args.stack_candidates, dtype=tdtype, capacity=cap, positions=sh0.positions)
-        probe["note"] = ("set-up, untimed (EnvSet.pickStackBuffer): 3 stack writes timed on each candidate buffer -- plain torch.empty "
-                         "allocations of the same size, one after the other -- the fastest kept, the others freed; candidate 0 is the "
-                         "allocation a caller gets by default")
+        sh0.stack, probe = sh0.envs.pickStackBuffer(args.stack_candidates, dtype=tdtype, capacity=cap, positions=sh0.positions, kinds=kinds)
+        probe["note"] = ("set-up, untimed (EnvSet.pickStackBuffer): 3 stack writes timed on each candidate buffer, the fastest kept, "
+                         "the others freed; candidate 0 is the allocation a caller gets by default (torch.empty), 'chunked' is "
+                         "T.alloc_stack = tq_stack_alloc (2 MiB physical chunks)")
 
     graph = None
     if args.graph:

@@ -88,6 +88,14 @@ int tq_set_min_qubit_errors(tq_env* h, int n_errors);
 /* p_error schedule of the actor's reset policy (Actor_mp.py:41-46,176-180) for tq_actor_step. */
 int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_final, double p_delta);
 
+/* Set-up helper for the caller-owned stack buffer (np.concatenate's result, numba/util_actor.py:37-39, written every
+ * step): device memory of at least `bytes` bytes backed by 2 MiB physical chunks (HIP virtual memory API).  Where a
+ * buffer lies in HBM changes the rate of every write stream into it by up to 20 % on MI355X; buffers made of 2 MiB
+ * chunks were the fast kind in nearly every run (profiles/r03_stack_write_ab.txt).  Allocates and synchronises; any
+ * other device allocation works as `out` of tq_persp_write just as well. */
+int tq_stack_alloc(int device, uint64_t bytes, void** out);
+int tq_stack_free(void* ptr);
+
 int tq_num_envs(const tq_env* h);
 int tq_size(const tq_env* h);
 

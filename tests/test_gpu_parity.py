@@ -765,3 +765,43 @@ def test_stack_ranges_whose_lattice_count_is_a_multiple_of_64(T):
         assert torch.equal(buf[:k * nq], per[offh[a]:offh[b]].reshape(-1)) and bool((buf[k * nq:] == 7).all()), (a, b)
         assert torch.equal(pbuf[:3 * k], pos[offh[a]:offh[b]].reshape(-1)) and bool((pbuf[3 * k:] == -5).all()), (a, b)
     gpu.close()
+
+
+def test_chunked_stack_buffer_and_placement_probe(T):
+    """T.alloc_stack (tq_stack_alloc: 2 MiB physical chunks behind one virtual range) is an ordinary device buffer for
+    the stack write -- same bytes as a torch.empty buffer, nothing written past the stack -- and
+    EnvSet.pickStackBuffer returns one of its candidates with the report of the probe."""
+    import ctypes as C
+    d, n = 7, 3000
+    gpu, ora = make_pair(T, d, n, seed=15, numpy_io=False)
+    gpu.resetAll()
+    ora.resetAll()
+    cnt, off = gpu.perspectiveCounts()
+    P = int(off[-1].item())
+    bp, bpos, _, _ = O.generate_perspective_batch(ora.states)
+    cap = P + 3
+    ref = torch.full((cap, 2, d, d), 7.0, dtype=torch.float32, device=gpu.device)
+    chk = T.alloc_stack(cap, d, torch.float32, gpu.device)
+    assert chk.shape == (cap, 2, d, d) and chk.is_cuda and chk.data_ptr() % (2 << 20) == 0
+    chk.fill_(7.0)
+    pos = torch.empty((cap, 3), dtype=torch.int32, device=gpu.device)
+    gpu.writePerspectives(ref, pos, off)
+    gpu.writePerspectives(chk, pos, off)
+    gpu.check()
+    assert torch.equal(ref, chk) and bool((chk[P:] == 7).all())
+    assert np.array_equal(chk[:P].cpu().numpy(), bp.astype(np.float32)) and np.array_equal(pos[:P].cpu().numpy(), bpos)
+    for dt in (torch.bfloat16, torch.uint8):
+        c2 = T.alloc_stack(P, d, dt, gpu.device)
+        gpu.writePerspectives(c2, None, off)
+        assert np.array_equal(c2.float().cpu().numpy(), bp.astype(np.float32))
+        del c2
+    best, rep = gpu.pickStackBuffer(4, capacity=cap, positions=pos)
+    assert rep["candidates"] == 4 and len(rep["write_ms"]) == 4 and 0 <= rep["chosen"] < 4
+    assert rep["kinds"][0] == "torch.empty" and "2 MiB" in rep["kinds"][1] and best.shape == (cap, 2, d, d)
+    gpu.writePerspectives(best, pos, off)
+    assert torch.equal(best[:P], ref[:P])
+    L = T.load()
+    assert L.tq_stack_free(C.c_void_p(ref.data_ptr())) == -1 and b"tq_stack_alloc" in L.tq_last_error()   # not one of ours
+    assert L.tq_stack_free(None) == 0
+    del chk, best
+    gpu.close()

@@ -25,6 +25,8 @@ SYMBOLS = [
     ("tq_set_params", _i, [_vp, _d, _d, _i]),
     ("tq_set_min_qubit_errors", _i, [_vp, _i]),
     ("tq_set_perror_schedule", _i, [_vp, _i, _d, _d, _d]),
+    ("tq_stack_alloc", _i, [_i, _u64, C.POINTER(_vp)]),
+    ("tq_stack_free", _i, [_vp]),
     ("tq_num_envs", _i, [_vp]),
     ("tq_size", _i, [_vp]),
     ("tq_reset_all", _i, [_vp, _vp, _vp]),

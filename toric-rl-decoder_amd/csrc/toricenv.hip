@@ -239,6 +239,80 @@ struct DeviceGuard {
 extern "C" {
 
 int tq_version(void) { return TQ_VERSION; }
+
+// ---- stack buffers backed by 2 MiB physical chunks (HIP virtual memory API)
+namespace {
+struct ChunkedAlloc { void* va; size_t bytes; int device; };
+std::mutex g_alloc_mu;
+ChunkedAlloc g_allocs[64];
+int g_n_allocs = 0;
+}  // namespace
+
+int tq_stack_alloc(int device, uint64_t bytes, void** out) {
+    if (!out) return fail(TQ_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (bytes == 0) return fail(TQ_E_INVALID, "bytes must be > 0");
+    DeviceGuard guard;
+    if (int rc = guard.enter_device(device)) return rc;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    HIPCHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    size_t chunk = (size_t)2 << 20;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = ((size_t)bytes + chunk - 1) / chunk;
+    void* va = nullptr;
+    HIPCHECK(hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0));
+    size_t mapped = 0;
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+        hipMemGenericAllocationHandle_t hnd;
+        e = hipMemCreate(&hnd, chunk, &prop, 0);
+        if (e != hipSuccess) break;
+        e = hipMemMap((char*)va + i * chunk, chunk, 0, hnd, 0);
+        (void)hipMemRelease(hnd);                            // the mapping keeps the memory alive
+        if (e == hipSuccess) ++mapped;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, n * chunk, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        if (mapped) (void)hipMemUnmap(va, mapped * chunk);
+        (void)hipMemAddressFree(va, n * chunk);
+        return fail(TQ_E_HIP, "chunked allocation of %llu bytes failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lock(g_alloc_mu);
+    if (g_n_allocs >= 64) {
+        (void)hipMemUnmap(va, n * chunk);
+        (void)hipMemAddressFree(va, n * chunk);
+        return fail(TQ_E_CAPACITY, "too many live tq_stack_alloc buffers (64)");
+    }
+    g_allocs[g_n_allocs++] = ChunkedAlloc{va, n * chunk, device};
+    *out = va;
+    return TQ_OK;
+}
+
+int tq_stack_free(void* ptr) {
+    if (!ptr) return TQ_OK;
+    ChunkedAlloc a{nullptr, 0, 0};
+    {
+        std::lock_guard<std::mutex> lock(g_alloc_mu);
+        for (int i = 0; i < g_n_allocs; ++i)
+            if (g_allocs[i].va == ptr) { a = g_allocs[i]; g_allocs[i] = g_allocs[--g_n_allocs]; break; }
+    }
+    if (!a.va) return fail(TQ_E_INVALID, "pointer did not come from tq_stack_alloc");
+    DeviceGuard guard;
+    if (int rc = guard.enter_device(a.device)) return rc;
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemUnmap(a.va, a.bytes));
+    HIPCHECK(hipMemAddressFree(a.va, a.bytes));
+    return TQ_OK;
+}
 const char* tq_last_error(void) { return g_err; }
 
 int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_t first_env_id) {

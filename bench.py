@@ -80,13 +80,14 @@ def parse(argv=None):
                          "its own PCIe link (0 = auto: 2 from 8 ranks on, where one Gen5 x16 link no longer carries "
                          "the ~63 GB/s of packed records; 1 below)")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
-    ap.add_argument("--stack-candidates", type=int, default=8,
+    ap.add_argument("--stack-candidates", type=int, default=12,
                     help="stack buffers to allocate at set-up; the one the write kernel is fastest on is kept, the others are "
                          "freed (where a buffer lies in HBM changes the write rate by up to 20 %% on this part: "
                          "profiles/r03_stack_write_ab.txt; the probe stops at the first candidate that is 14 %% faster than the "
                          "first).  1 = take the first allocation as it comes")
     ap.add_argument("--stack-kinds", default="torch,chunked",
-                    help="where candidate k comes from, cyclically: torch = torch.empty, chunked = T.alloc_stack (2 MiB physical "
+                    help="where the candidates come from (first entry: candidate 0, the rest cyclically for the others): torch = "
+                         "torch.empty, chunked = T.alloc_stack (2 MiB physical "
                          "chunks, tq_stack_alloc).  Profile runs use --stack-candidates 1 --stack-kinds chunked so that every "
                          "launch of the process writes the same buffer")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
@@ -211,10 +212,14 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
         if idx.numel():
             envs.resetTerminalEnvs(idx)
         envs.actorStep(None, want_actions=False)
+    probe = None
+    if chunks > 1 and "chunked" in kinds:                             # the small buffer of the range-by-range consumer: 2 MiB chunks, no probe
+        del stack
+        stack = T.alloc_stack((n // chunks) * nq, d, tdtype, device)
     if candidates > 1 and chunks == 1:                               # placement probe, as in the main loop
         del stack
         torch.cuda.empty_cache()
-        stack, _ = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions, kinds=kinds)
+        stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions, kinds=kinds, park=True)
 
     def step(t):
         off = offs[t][:n + 1]
@@ -243,8 +248,12 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
     dt = time.perf_counter() - t0
     P = float(offs[warm:, n].sum().item())
     envs.check()
-    envs.close()
+    envs.close()                                                    # frees the parked candidates of the probe as well ...
+    del stack
+    torch.cuda.empty_cache()
+    time.sleep(0.5)                                                 # ... and the driver wipes freed memory in the background
     ev_ms = np.array([a.elapsed_time(b) for a, b in ev]) if ev is not None else None
+    time_plain_loop.last_probe = probe
     return dt, P, ev_ms
 
 
@@ -488,7 +497,9 @@ def main():
         sh0 = shards[0]
         del sh0.stack
         torch.cuda.empty_cache()
-        sh0.stack, probe = sh0.envs.pickStackBuffer(args.stack_candidates, dtype=tdtype, capacity=cap, positions=sh0.positions, kinds=kinds)
+        # rejected candidates stay parked until the timed region is over: the driver wipes freed memory in the background
+        sh0.stack, probe = sh0.envs.pickStackBuffer(args.stack_candidates, dtype=tdtype, capacity=cap, positions=sh0.positions, kinds=kinds,
+                                                    park=True)
         probe["note"] = ("set-up, untimed (EnvSet.pickStackBuffer): 3 stack writes timed on each candidate buffer, the fastest kept, "
                          "the others freed; candidate 0 is the allocation a caller gets by default (torch.empty), 'chunked' is "
                          "T.alloc_stack = tq_stack_alloc (2 MiB physical chunks)")
@@ -540,6 +551,8 @@ def main():
     elapsed = timed_region(0)
     for sh in shards:
         sh.envs.check()                                               # capacity / action / reset latch
+        sh.envs.releaseParked()
+    time.sleep(0.5)
 
     if graph is not None:      # slot t of the captured window accumulated its P over the K/flush replays
         p_timed = (p_acc.to(torch.float64) / (K // flush)).repeat(K // flush).reshape(1, -1)
@@ -570,7 +583,7 @@ def main():
         print("[bench] configs[4] shard leg (131072 lattices on this GPU) ...", file=sys.stderr, flush=True)
         dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
-                     "perspectives_per_sec": P2 / dt2,
+                     "perspectives_per_sec": P2 / dt2, "stack_buffer_probe": time_plain_loop.last_probe,
                      "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
                              "no collective: the like-for-like base of the scaling curve"}
 
@@ -589,6 +602,7 @@ def main():
                                            candidates=args.stack_candidates)
             alg3 = P3 / k3 * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
             c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
+                            "stack_buffer_probe": time_plain_loop.last_probe,
                             "perspectives_per_sec": P3 / dt3, "perspectives_per_lattice": P3 / (k3 * n3),
                             "roofline": {"bound": "hbm", "kernel": STACK_KERNEL, "achieved": alg3 / (ev3.mean() * 1e-3) / 1e9,
                                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg3 / (ev3.mean() * 1e-3) / 1e9 / HBM_PEAK_GBPS,

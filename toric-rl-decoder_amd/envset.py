@@ -268,6 +268,7 @@ class EnvSet:
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
+        self._parked = []
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.tq_destroy(self._h)
             self._h = C.c_void_p(None)
@@ -411,17 +412,21 @@ class EnvSet:
         self._positions = positions
 
     def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=3,
-                        kinds=("torch", "chunked"), good_enough=0.86):
+                        kinds=("torch", "chunked"), good_enough=0.86, park=False):
         """Set-up helper: allocate ``candidates`` stack buffers (``capacity`` perspectives each, default the worst
         case no_envs * 2*d*d), time the stack write of the CURRENT lattices on each of them and keep the fastest.
         Where a buffer lies in HBM changes the rate of ANY write stream into it by up to 20 % on MI355X (a plain fill
         included; profiles/r03_stack_write_ab.txt), and a caller writes the same buffer every step, so the choice is
-        worth a few launches at set-up.  ``kinds``: where candidate k comes from, cyclically -- "torch" = torch.empty
-        (candidate 0 by default: what a caller gets without this helper), "chunked" = alloc_stack (2 MiB physical
-        chunks: 6.5-6.7 TB/s against 5.2-5.5 for plain allocations in most runs).  -> (stack tensor (capacity,2,d,d),
+        worth a few launches at set-up.  ``kinds``: where the candidates come from -- kinds[0] for candidate 0, the
+        rest cyclically for the others: "torch" = torch.empty (candidate 0 by default: what a caller gets without this
+        helper), "chunked" = alloc_stack (2 MiB physical chunks: 6.5-6.7 TB/s against 5.2-5.5 for plain allocations
+        in most runs).  -> (stack tensor (capacity,2,d,d),
         report dict with the ms and kind of every candidate).  The probe stops early once a candidate takes less than
         ``good_enough`` x the time of candidate 0 (the two kinds of placement are ~20 % apart, nothing lies in
-        between).  Synchronises; never call it in the step loop."""
+        between).  ``park``: keep the rejected candidates allocated until releaseParked() / close() instead of
+        freeing them here -- the driver wipes freed device memory in the background, tens of GB of it take HBM
+        bandwidth away from whatever runs in the next tens of milliseconds (a benchmark's timed region, say).
+        Synchronises; never call it in the step loop."""
         d, nq = self.size, 2 * self.size * self.size
         cap = self.no_envs * nq if capacity is None else int(capacity)
         if positions is None:
@@ -432,7 +437,7 @@ class EnvSet:
         ms, keep = [], []          # every candidate stays allocated until the choice is made: distinct placements
         used = []
         for k in range(max(1, int(candidates))):
-            kind = kinds[k % len(kinds)]
+            kind = kinds[0] if k == 0 or len(kinds) == 1 else kinds[1 + (k - 1) % (len(kinds) - 1)]
             c = None
             if kind == "chunked":
                 try:
@@ -455,9 +460,17 @@ class EnvSet:
                 break
         self.check()
         best = keep[int(np.argmin(ms))]
+        if park:
+            self._parked = getattr(self, "_parked", []) + [x for x in keep if x is not best]
         del keep, c
-        torch.cuda.empty_cache()
+        if not park:
+            torch.cuda.empty_cache()
         return best, {"candidates": len(ms), "write_ms": ms, "chosen": int(np.argmin(ms)), "kinds": used}
+
+    def releaseParked(self):
+        """Free the candidates pickStackBuffer(park=True) kept."""
+        self._parked = []
+        torch.cuda.empty_cache()
 
     def generatePerspective(self, states=None, dtype=torch.float32):
         """generatePerspectiveBatch + concatenate (numba/util_actor.py:33-39,56-67) for the current

@@ -213,13 +213,14 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
             envs.resetTerminalEnvs(idx)
         envs.actorStep(None, want_actions=False)
     probe = None
-    if chunks > 1 and "chunked" in kinds:                             # the small buffer of the range-by-range consumer: 2 MiB chunks, no probe
-        del stack
-        stack = T.alloc_stack((n // chunks) * nq, d, tdtype, device)
-    if candidates > 1 and chunks == 1:                               # placement probe, as in the main loop
+    if candidates > 1:                                               # placement probe, as in the main loop
         del stack
         torch.cuda.empty_cache()
-        stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions, kinds=kinds, park=True)
+        if chunks == 1:
+            stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions, kinds=kinds, park=True)
+        else:                                                        # the small buffer of the range-by-range consumer, probed with the first range
+            stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, capacity=(n // chunks) * nq, positions=positions, kinds=kinds,
+                                                park=True, first=0, count=n // chunks)
 
     def step(t):
         off = offs[t][:n + 1]

@@ -104,6 +104,10 @@ def test_bench_json_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["one_core"]["value"] > 0
     nn = j["nn_in_loop"]
     assert nn["steps"] == 1 and nn["perspectives_per_sec_into_nn"] > 1e4 and nn["env_steps_per_sec"] > 100
+    assert set(nn["variants"]) == {"f32", "bf16"} and nn["variants"]["bf16"]["stack_dtype"] == "bf16"
+    pr = j["stack_buffer_probe"]                              # set-up probe of the stack buffer's placement, reported in full
+    assert pr["kinds"][0] == "torch.empty" and len(pr["write_ms"]) == pr["candidates"] >= 2 and 0 <= pr["chosen"] < pr["candidates"]
+    assert r["kernel"] == "k_persp_stream" and "custom" in j["config"]["workload"]      # 8192 lattices: not a BASELINE config
     assert j["config"]["steady_state"] is True and 40 < j["perspectives_per_lattice"] < 98
     assert j["value"] > 1e6 and abs(j["value"] - 8192 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6
 

@@ -11,6 +11,7 @@
 
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "kernels.hpp"
 #include "stream_write.hpp"
@@ -244,8 +245,7 @@ int tq_version(void) { return TQ_VERSION; }
 namespace {
 struct ChunkedAlloc { void* va; size_t bytes; int device; };
 std::mutex g_alloc_mu;
-ChunkedAlloc g_allocs[64];
-int g_n_allocs = 0;
+std::vector<ChunkedAlloc> g_allocs;
 }  // namespace
 
 int tq_stack_alloc(int device, uint64_t bytes, void** out) {
@@ -287,12 +287,7 @@ int tq_stack_alloc(int device, uint64_t bytes, void** out) {
         return fail(TQ_E_HIP, "chunked allocation of %llu bytes failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
     }
     std::lock_guard<std::mutex> lock(g_alloc_mu);
-    if (g_n_allocs >= 64) {
-        (void)hipMemUnmap(va, n * chunk);
-        (void)hipMemAddressFree(va, n * chunk);
-        return fail(TQ_E_CAPACITY, "too many live tq_stack_alloc buffers (64)");
-    }
-    g_allocs[g_n_allocs++] = ChunkedAlloc{va, n * chunk, device};
+    g_allocs.push_back(ChunkedAlloc{va, n * chunk, device});
     *out = va;
     return TQ_OK;
 }
@@ -302,8 +297,8 @@ int tq_stack_free(void* ptr) {
     ChunkedAlloc a{nullptr, 0, 0};
     {
         std::lock_guard<std::mutex> lock(g_alloc_mu);
-        for (int i = 0; i < g_n_allocs; ++i)
-            if (g_allocs[i].va == ptr) { a = g_allocs[i]; g_allocs[i] = g_allocs[--g_n_allocs]; break; }
+        for (size_t i = 0; i < g_allocs.size(); ++i)
+            if (g_allocs[i].va == ptr) { a = g_allocs[i]; g_allocs[i] = g_allocs.back(); g_allocs.pop_back(); break; }
     }
     if (!a.va) return fail(TQ_E_INVALID, "pointer did not come from tq_stack_alloc");
     DeviceGuard guard;

@@ -412,7 +412,7 @@ class EnvSet:
         self._positions = positions
 
     def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=3,
-                        kinds=("torch", "chunked"), good_enough=0.86, park=False):
+                        kinds=("torch", "chunked"), good_enough=0.86, park=False, first=0, count=None):
         """Set-up helper: allocate ``candidates`` stack buffers (``capacity`` perspectives each, default the worst
         case no_envs * 2*d*d), time the stack write of the CURRENT lattices on each of them and keep the fastest.
         Where a buffer lies in HBM changes the rate of ANY write stream into it by up to 20 % on MI355X (a plain fill
@@ -426,7 +426,8 @@ class EnvSet:
         between).  ``park``: keep the rejected candidates allocated until releaseParked() / close() instead of
         freeing them here -- the driver wipes freed device memory in the background, tens of GB of it take HBM
         bandwidth away from whatever runs in the next tens of milliseconds (a benchmark's timed region, say).
-        Synchronises; never call it in the step loop."""
+        ``first`` / ``count``: time the write of that lattice range only (a consumer that walks the batch in ranges
+        with a small buffer: ``capacity`` is then the small buffer's).  Synchronises; never call it in the step loop."""
         d, nq = self.size, 2 * self.size * self.size
         cap = self.no_envs * nq if capacity is None else int(capacity)
         if positions is None:
@@ -451,7 +452,7 @@ class EnvSet:
             t = []
             for r in range(int(launches) + 1):
                 e0.record()
-                self.writePerspectives(c, positions, off)
+                self.writePerspectives(c, positions, off, first=first, count=count)
                 e1.record()
                 e1.synchronize()
                 t.append(e0.elapsed_time(e1))

@@ -71,6 +71,8 @@ def parse(argv=None):
     ap.add_argument("--chunks", type=int, default=1,
                     help="write the stack of a step in this many lattice ranges, one after the other, into ONE buffer "
                          "of 1/chunks the size (tq_persp_write_range; a consumer with a small buffer, SURVEY 8d C4)")
+    ap.add_argument("--separate-scan", action="store_true",
+                    help="tq_persp_count + tq_persp_write (two launches per step) instead of tq_persp_count_write (one): A/B")
     ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
     ap.add_argument("--delivery", default="auto", choices=["auto", "host", "hbm"],
                     help="N>1: where gathered transition blocks end up. host = pinned host replay ring (default for "
@@ -193,7 +195,7 @@ class Shard:
 
 
 def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False, candidates=1,
-                    kinds=("torch", "chunked")):
+                    kinds=("torch", "chunked"), separate_scan=False):
     """The same pass over a batch of `n` lattices on the current stream, no collective: burn-in, `warm` untimed
     and `steps` timed steps.  -> (seconds, perspectives in the timed steps, per-step stack-write milliseconds
     from HIP events or None).  Used at N=1 for the extra legs of the line: one GPU on the per-GPU shape of the
@@ -224,10 +226,13 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
 
     def step(t):
         off = offs[t][:n + 1]
-        envs.perspectiveCounts(off)
+        if chunks > 1 or separate_scan:
+            envs.perspectiveCounts(off)
         if ev is not None and t >= warm:
             ev[t - warm][0].record()
-        if chunks == 1:
+        if chunks == 1 and not separate_scan:
+            envs.countAndWritePerspectives(stack, positions, off)
+        elif chunks == 1:
             envs.writePerspectives(stack, positions, off)
         else:
             for c in range(chunks):
@@ -429,18 +434,23 @@ def main():
     tg = make_gathers(host_delivery)
     state = {"tg": tg, "model": model}
 
+    one_launch = CH == 1 and not args.separate_scan
+
     def one_step(k, t, timed_idx=None):
         sh = shards[k]
         tg_, model_ = state["tg"], state["model"]
         # one shard: stay on torch's current stream (inside torch.cuda.graph() that is the capture stream)
         with (torch.cuda.stream(sh.stream) if S > 1 else contextlib.nullcontext()):
             envs, off = sh.envs, sh.offs[t][:ns + 1]
-            envs.perspectiveCounts(off)
+            if not one_launch:
+                envs.perspectiveCounts(off)
             if S > 1:
                 sh.stream.wait_event(shards[(k - 1) % S].wrote)          # one stack write at a time
             if timed_idx is not None and use_events:
                 sh.ev[timed_idx][0].record(sh.stream)
-            if CH == 1:
+            if one_launch:                                            # scan + write in one launch (tq_persp_count_write)
+                envs.countAndWritePerspectives(sh.stack, sh.positions, off)
+            elif CH == 1:
                 envs.writePerspectives(sh.stack, sh.positions, off)
             else:                                                     # the consumer would read the buffer between two chunks
                 for c in range(CH):
@@ -582,7 +592,8 @@ def main():
     if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore" and not args.no_shard_leg:
         k2, w2 = max(8, min(K, 40)), 8
         print("[bench] configs[4] shard leg (131072 lattices on this GPU) ...", file=sys.stderr, flush=True)
-        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates)
+        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates,
+                                     separate_scan=args.separate_scan)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
                      "perspectives_per_sec": P2 / dt2, "stack_buffer_probe": time_plain_loop.last_probe,
                      "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
@@ -600,7 +611,7 @@ def main():
         for name, ch in (("one_shot", 1), ("chunks_4", 4)):
             print("[bench] configs[3] leg (65536 lattices, d=9, p=0.15), %s ..." % name, file=sys.stderr, flush=True)
             dt3, P3, ev3 = time_plain_loop(T, torch, env3, n3, d3, args.seed, 0, tdtype, flush, device, k3, w3, chunks=ch, events=True,
-                                           candidates=args.stack_candidates)
+                                           candidates=args.stack_candidates, separate_scan=args.separate_scan)
             alg3 = P3 / k3 * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
             c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
                             "stack_buffer_probe": time_plain_loop.last_probe,
@@ -715,7 +726,9 @@ def main():
                                "measured_fill_gbps": fill_gbps, "frac_of_measured_fill": achieved / fill_gbps,
                                "bytes_per_launch": alg, "avg_launch_ms": float(ev_ms.mean()),
                                "median_launch_ms": float(np.median(ev_ms)), "perspectives_per_launch": p_mean,
-                               "launches_per_step": S * CH, "lattices_per_launch": ns // CH}
+                               "launches_per_step": S * CH, "lattices_per_launch": ns // CH,
+                               "scan": "inside the timed launch (tq_persp_count_write: the write kernel scans the counts in its "
+                                       "prologue)" if one_launch else "separate launch before the timed one (tq_persp_count)"}
         if nn_leg is not None:
             res["nn_in_loop"] = nn_leg
         if world == 1 and args.cpu_seconds > 0:

@@ -411,6 +411,26 @@ class EnvSet:
                        _DTYPES[out.dtype])
         self._positions = positions
 
+    def countAndWritePerspectives(self, out, positions=None, offsets=None):
+        """perspectiveCounts + writePerspectives in ONE launch (tq_persp_count_write) for a caller that already owns
+        the stack buffer ``out``: the scan runs in the prologue of the write kernel.  ``offsets``: optional
+        caller-owned int64[N+1] tensor that receives the scan.  -> (counts, offsets); no synchronisation.  A stack that
+        does not fit ``out`` latches TQ_E_CAPACITY (check())."""
+        if out.dtype not in _DTYPES or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32/float16/bfloat16/uint8 tensor")
+        nq = 2 * self.size * self.size
+        cap = out.numel() // nq
+        if positions is not None and (positions.dtype != torch.int32 or positions.numel() < 3 * cap):
+            raise ValueError("positions must be int32 with at least 3*capacity elements")
+        if offsets is not None:
+            if offsets.dtype != torch.int64 or offsets.numel() != self.no_envs + 1 or not offsets.is_contiguous():
+                raise ValueError("offsets must be a contiguous int64 tensor of no_envs + 1 elements")
+            self._offsets = offsets
+        self._call(self._L.tq_persp_count_write, _ptr(self._counts), _ptr(self._offsets), _ptr(out), _ptr(positions), cap,
+                   _DTYPES[out.dtype])
+        self._positions = positions
+        return self._counts, self._offsets
+
     def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=3,
                         kinds=("torch", "chunked"), good_enough=0.86, park=False, first=0, count=None):
         """Set-up helper: allocate ``candidates`` stack buffers (``capacity`` perspectives each, default the worst

@@ -71,8 +71,10 @@ def parse(argv=None):
     ap.add_argument("--chunks", type=int, default=1,
                     help="write the stack of a step in this many lattice ranges, one after the other, into ONE buffer "
                          "of 1/chunks the size (tq_persp_write_range; a consumer with a small buffer, SURVEY 8d C4)")
-    ap.add_argument("--separate-scan", action="store_true",
-                    help="tq_persp_count + tq_persp_write (two launches per step) instead of tq_persp_count_write (one): A/B")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="bracket every E-th stack write of the timed region with HIP events (roofline). A hipEventRecord "
+                         "costs ~3 us of stream time on MI355X (tools/ab_scan.py), so bracketing every launch adds 6 us to "
+                         "every step of the timed region; 1 = every launch")
     ap.add_argument("--no-transitions", action="store_true", help="do not write transition records")
     ap.add_argument("--delivery", default="auto", choices=["auto", "host", "hbm"],
                     help="N>1: where gathered transition blocks end up. host = pinned host replay ring (default for "
@@ -195,7 +197,7 @@ class Shard:
 
 
 def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False, candidates=1,
-                    kinds=("torch", "chunked"), separate_scan=False):
+                    kinds=("torch", "chunked"), event_every=4):
     """The same pass over a batch of `n` lattices on the current stream, no collective: burn-in, `warm` untimed
     and `steps` timed steps.  -> (seconds, perspectives in the timed steps, per-step stack-write milliseconds
     from HIP events or None).  Used at N=1 for the extra legs of the line: one GPU on the per-GPU shape of the
@@ -208,7 +210,9 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
     positions = torch.empty(((n // chunks) * nq, 3), dtype=torch.int32, device=device)
     offs = torch.zeros((warm + steps, (n + 2) & ~1), dtype=torch.int64, device=device)
     blocks = [envs.newTransitionBlock(steps=flush) for _ in range(2)]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if events else None
+    every = max(1, min(int(event_every), steps))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range((steps + every - 1) // every)] if events else None
     for t in range(EPISODE):
         idx = torch.arange(t, n, EPISODE, dtype=torch.int32, device=device)
         if idx.numel():
@@ -226,19 +230,17 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
 
     def step(t):
         off = offs[t][:n + 1]
-        if chunks > 1 or separate_scan:
-            envs.perspectiveCounts(off)
-        if ev is not None and t >= warm:
-            ev[t - warm][0].record()
-        if chunks == 1 and not separate_scan:
-            envs.countAndWritePerspectives(stack, positions, off)
-        elif chunks == 1:
+        envs.perspectiveCounts(off)
+        timed = ev is not None and t >= warm and (t - warm) % every == 0
+        if timed:
+            ev[(t - warm) // every][0].record()
+        if chunks == 1:
             envs.writePerspectives(stack, positions, off)
         else:
             for c in range(chunks):
                 envs.writePerspectives(stack, positions, off, first=c * (n // chunks), count=n // chunks)
-        if ev is not None and t >= warm:
-            ev[t - warm][1].record()
+        if timed:
+            ev[(t - warm) // every][1].record()
         blk = blocks[(t // flush) & 1]
         envs.actorStep(None, block=blk, slot=t % flush, want_actions=True)
         if (t + 1) % flush == 0:
@@ -253,6 +255,7 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     P = float(offs[warm:, n].sum().item())
+    time_plain_loop.last_p_bracketed = float(offs[warm::every, n].double().mean().item())   # per step, of the steps the events bracket
     envs.check()
     envs.close()                                                    # frees the parked candidates of the probe as well ...
     del stack
@@ -379,6 +382,7 @@ def main():
     ns = n // S
     flush = max(1, args.flush)
     use_events = not args.no_events and not args.graph
+    EV = max(1, min(args.event_every, K))
     if args.policy == "nn11" and args.chunks > 1:
         sys.exit("--policy nn11 reads the whole stack: use --chunks 1")
     if args.graph and (args.policy != "explore" or world > 1 or args.shards != 1):
@@ -418,7 +422,7 @@ def main():
             sh.offs = torch.zeros((2 * (W + K) + 2 * args.nn_steps + 4, row), dtype=torch.int64, device=device)  # one scan per step: P = row[ns]
             sh.blocks = None if args.no_transitions else [sh.envs.newTransitionBlock(steps=flush) for _ in range(2)]
             sh.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                     for _ in range(K)] if use_events else []
+                     for _ in range((K + EV - 1) // EV)] if use_events else []
             sh.wrote = torch.cuda.Event()
             sh.eps = torch.full((ns,), args.eps, dtype=torch.float64, device=device)
             sh.burn_idx = [torch.arange(t, ns, EPISODE, dtype=torch.int32, device=device) for t in range(EPISODE)]
@@ -434,29 +438,25 @@ def main():
     tg = make_gathers(host_delivery)
     state = {"tg": tg, "model": model}
 
-    one_launch = CH == 1 and not args.separate_scan
-
     def one_step(k, t, timed_idx=None):
         sh = shards[k]
         tg_, model_ = state["tg"], state["model"]
         # one shard: stay on torch's current stream (inside torch.cuda.graph() that is the capture stream)
         with (torch.cuda.stream(sh.stream) if S > 1 else contextlib.nullcontext()):
             envs, off = sh.envs, sh.offs[t][:ns + 1]
-            if not one_launch:
-                envs.perspectiveCounts(off)
+            envs.perspectiveCounts(off)
             if S > 1:
                 sh.stream.wait_event(shards[(k - 1) % S].wrote)          # one stack write at a time
-            if timed_idx is not None and use_events:
-                sh.ev[timed_idx][0].record(sh.stream)
-            if one_launch:                                            # scan + write in one launch (tq_persp_count_write)
-                envs.countAndWritePerspectives(sh.stack, sh.positions, off)
-            elif CH == 1:
+            bracket = timed_idx is not None and use_events and timed_idx % EV == 0
+            if bracket:
+                sh.ev[timed_idx // EV][0].record(sh.stream)
+            if CH == 1:
                 envs.writePerspectives(sh.stack, sh.positions, off)
             else:                                                     # the consumer would read the buffer between two chunks
                 for c in range(CH):
                     envs.writePerspectives(sh.stack, sh.positions, off, first=c * (ns // CH), count=ns // CH)
-            if timed_idx is not None and use_events:
-                sh.ev[timed_idx][1].record(sh.stream)
+            if bracket:
+                sh.ev[timed_idx // EV][1].record(sh.stream)
             if S > 1:
                 sh.wrote.record(sh.stream)
             blk = sh.blocks[(t // flush) & 1] if have_blocks else None
@@ -592,8 +592,7 @@ def main():
     if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore" and not args.no_shard_leg:
         k2, w2 = max(8, min(K, 40)), 8
         print("[bench] configs[4] shard leg (131072 lattices on this GPU) ...", file=sys.stderr, flush=True)
-        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates,
-                                     separate_scan=args.separate_scan)
+        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
                      "perspectives_per_sec": P2 / dt2, "stack_buffer_probe": time_plain_loop.last_probe,
                      "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
@@ -611,8 +610,8 @@ def main():
         for name, ch in (("one_shot", 1), ("chunks_4", 4)):
             print("[bench] configs[3] leg (65536 lattices, d=9, p=0.15), %s ..." % name, file=sys.stderr, flush=True)
             dt3, P3, ev3 = time_plain_loop(T, torch, env3, n3, d3, args.seed, 0, tdtype, flush, device, k3, w3, chunks=ch, events=True,
-                                           candidates=args.stack_candidates, separate_scan=args.separate_scan)
-            alg3 = P3 / k3 * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
+                                           candidates=args.stack_candidates, event_every=args.event_every)
+            alg3 = time_plain_loop.last_p_bracketed * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
             c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
                             "stack_buffer_probe": time_plain_loop.last_probe,
                             "perspectives_per_sec": P3 / dt3, "perspectives_per_lattice": P3 / (k3 * n3),
@@ -620,8 +619,8 @@ def main():
                                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg3 / (ev3.mean() * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                          "bytes_per_step": alg3, "avg_write_ms_per_step": float(ev3.mean()),
                                          "launches_per_step": ch,
-                                         "note": "HIP events around the stack write(s) of every timed step%s" %
-                                                 ("" if ch == 1 else ": the %d range launches and their gaps included (every workgroup finds its own cut points)" % ch)}}
+                                         "note": "HIP events around the stack write(s) of every %d. timed step%s" % (max(1, min(args.event_every, k3)),
+                                                 ("" if ch == 1 else ": the %d range launches and their gaps included (every workgroup finds its own cut points)" % ch))}}
 
     # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured at size in
     # f32 (what upstream runs) and with the bf16 stack the kernels can write directly + bf16 autocast
@@ -704,7 +703,7 @@ def main():
         if c3_leg is not None:
             res["configs3_on_one_gpu"] = c3_leg
         if use_events:
-            p_mean = float(p_timed.mean().item())
+            p_mean = float(p_timed[:, ::EV].mean().item())              # of the launches the events bracket
             alg = p_mean * (nq * esize + 12) + ns * nq                 # P*(B_p+12) + N*2d^2, per launch
             achieved = alg / (ev_ms.mean() * 1e-3) / 1e9
             traffic, ent = pmc_traffic(d, args.out_dtype, n, args.p_error, S * CH, p_mean)
@@ -727,8 +726,9 @@ def main():
                                "bytes_per_launch": alg, "avg_launch_ms": float(ev_ms.mean()),
                                "median_launch_ms": float(np.median(ev_ms)), "perspectives_per_launch": p_mean,
                                "launches_per_step": S * CH, "lattices_per_launch": ns // CH,
-                               "scan": "inside the timed launch (tq_persp_count_write: the write kernel scans the counts in its "
-                                       "prologue)" if one_launch else "separate launch before the timed one (tq_persp_count)"}
+                               "launches_timed": int(ev_ms.size),
+                               "timed_launches": "every %d%s step of the timed region (a HIP event record costs ~3 us of stream time; "
+                                                 "--event-every 1 brackets every launch)" % (EV, "th" if EV > 3 else ("st", "nd", "rd")[EV - 1])}
         if nn_leg is not None:
             res["nn_in_loop"] = nn_leg
         if world == 1 and args.cpu_seconds > 0:

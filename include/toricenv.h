@@ -143,16 +143,6 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
 int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count, void* out,
                          int32_t* positions, int64_t capacity, int dtype, void* stream);
 
-/* Steps 1 and 2 in ONE launch, for the whole batch and a caller that already owns a stack buffer (the steady state of
- * the actor loop, Actor_mp.py:104-185: the buffer of the previous iteration is written again): the scan is done in
- * the prologue of the write kernel from the per-256-lattice sums the kernel that produced the counts left behind.
- * `offsets` i64[N+1] and `counts` i32[N] (may be NULL) are OUTPUTS exactly as from tq_persp_count; `out`,
- * `positions`, `capacity`, `dtype` as for tq_persp_write (a stack that does not fit: TQ_E_CAPACITY latched, the
- * lattices that fit whole are written, offsets complete).  Handles of more than 1 048 576 lattices take the two
- * launches of tq_persp_count + tq_persp_write inside this call; the results are the same. */
-int tq_persp_count_write(tq_env* h, int32_t* counts, int64_t* offsets, void* out, int32_t* positions,
-                         int64_t capacity, int dtype, void* stream);
-
 /* Same two steps for a batch of syndromes that does not live in a handle (the learner's
  * predictMaxOptimized, util_learner.py:48-111): states = device u8[n,2,d,d]. */
 /* set-up: size the calling device's scratch for up to n_max states of size d (allocates, synchronises) */

@@ -1,8 +1,12 @@
-"""A/B in ONE process on ONE stack buffer: scan + write as two launches (tq_persp_count, tq_persp_write) against the
-one-launch form (tq_persp_count_write), alternating blocks of steps of the bench's plain actor-loop pass.
+"""A/B in ONE process on ONE stack buffer, alternating blocks of steps of the bench's plain actor-loop pass:
+  * scan + write as two launches (tq_persp_count, tq_persp_write) against the one-launch experiment
+    (tq_persp_count_write: the scan in the write kernel's prologue -- commit 2d73a3d has it, the library no longer does;
+    the one-launch rows are skipped when the entry point is absent),
+  * with and without a pair of HIP events around the write of every step.
     python tools/ab_scan.py [d] [p_error] [lattices] [rounds] [steps per block]
-Prints per-round wall-clock microseconds per step of each form (synchronised around every block) and the HIP-event
-time of the (count +) write launch(es)."""
+Prints wall-clock microseconds per step of each form (synchronised around every block) and the HIP-event time of the
+(count +) write launch(es).  Result (profiles/r03_stack_write_ab.txt, 10): the one-launch form gains nothing, a pair
+of event records costs 6 us per step."""
 import os
 import sys
 import time
@@ -59,9 +63,12 @@ def main():
         dt = time.perf_counter() - t0
         return 1e6 * dt / k, 1e3 * float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
 
-    block(True, 20), block(False, 20)
+    have_fused = hasattr(envs, "countAndWritePerspectives")
     forms = [("two launches, events", False, True), ("one launch, events", True, True),
              ("two launches, no events", False, False), ("one launch, no events", True, False)]
+    forms = [f for f in forms if have_fused or not f[1]]
+    for f in forms:
+        block(f[1], 20, f[2])
     res = {f[0]: [] for f in forms}
     for r in range(rounds):
         for name, fused, events in forms:

@@ -42,7 +42,6 @@ SYMBOLS = [
     ("tq_persp_count", _i, [_vp, _vp, _vp, _vp]),
     ("tq_persp_write", _i, [_vp, _vp, _vp, _vp, _i64, _i, _vp]),
     ("tq_persp_write_range", _i, [_vp, _vp, _i, _i, _vp, _vp, _i64, _i, _vp]),
-    ("tq_persp_count_write", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     ("tq_states_reserve", _i, [_i, _i]),
     ("tq_states_persp_count", _i, [_i, _i, _vp, _vp, _vp, _vp]),
     ("tq_states_persp_write", _i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),

@@ -78,34 +78,6 @@ struct StreamLds {
     uint32_t abort;
 };
 
-// ---- the scan folded into the write (SCAN): block-wide helpers over all NW waves of the workgroup
-__device__ __forceinline__ int wave_sum32(int x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
-}
-// exclusive scan of one int64 per thread over the workgroup (thread order); `total` = sum over the workgroup.
-// wt: 2 * NW LDS words used alternately (`par`), so one barrier per call is enough.
-template <int NW>
-__device__ __forceinline__ int64_t block_excl_scan64(int64_t x, int64_t* wt, int& par, int wave, int lane, int64_t& total) {
-    int64_t inc = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int64_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-    }
-    int64_t* w_ = wt + par * NW;
-    par ^= 1;
-    if (lane == 63) w_[wave] = inc;
-    __syncthreads();
-    int64_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { const int64_t t = w_[w]; tot += t; if (w < wave) base += t; }
-    total = tot;
-    return base + inc - x;
-}
-constexpr int SCAN_FUSE_MAX_PARTS = 4096;                      // level-1 sums the prologue can hold (N <= 1 048 576 lattices)
-
 // A cut point of a lattice range into G = 1 << LG parts of equal perspective count: the first lattice e in
 // [e_begin, e_end] with offsets[e] - offsets[e_begin] >= (total * k) >> LG.  One wavefront, 64-ary search (three
 // rounds of vector loads for 65 536 lattices); the result is wave-uniform.  k_scan_final writes the same numbers for
@@ -144,25 +116,13 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offse
 
 // STATS (diagnostic builds only, tools/stream_bench.hip): every wave leaves {cycles alive, cycles waiting (A), cycles
 // waiting (B), items} in stats[(block * waves + wave) * 4 ..]; A/B = storers: production / -, producers: ring room / commit turn.
-//
-// SCAN: the exclusive scan of the counts (tq_persp_count) is done HERE, in the prologue, for the whole batch
-// (e_begin = 0, e_end = N): `offsets_w` (i64[N+1]) is an OUTPUT, `offsets` / `split` are unused.  Inputs are what the
-// kernel that produced the counts left behind: counts i32[N] and the level-1 sums partial[ceil(N/256)]
-// (block_count_partial).  Every workgroup prefixes the level-1 sums (<= SCAN_FUSE_MAX_PARTS of them, in the LDS of the
-// not yet used ring), finds its two cut lattices in the 256-count block that holds each target, and then scans the
-// counts of ITS lattices, writing their offsets for the caller and for its own producers.  No workgroup reads what
-// another one wrote, so there is no grid-wide hand-over: one launch less per step than scan + write.
-template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false, bool SCAN = false>
+template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false>
 __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint64_t* __restrict__ vp, int64_t N,
-                                                                  const int64_t* offsets, OutT* __restrict__ out,
+                                                                  const int64_t* __restrict__ offsets, OutT* __restrict__ out,
                                                                   int32_t* __restrict__ pos, int64_t capacity,
                                                                   int* __restrict__ err, int64_t e_begin, int64_t e_end,
                                                                   const int32_t* __restrict__ split,
-                                                                  unsigned long long* __restrict__ stats = nullptr,
-                                                                  const int32_t* __restrict__ counts = nullptr,
-                                                                  const int64_t* __restrict__ partial = nullptr,
-                                                                  int64_t* offsets_w = nullptr,
-                                                                  int32_t* __restrict__ counts_out = nullptr) {
+                                                                  unsigned long long* __restrict__ stats = nullptr) {
     using L = Lat<D>;
     using PS = PStream<D>;
     unsigned long long t_begin = 0, t_a = 0, t_b = 0, n_items = 0;
@@ -190,161 +150,36 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
 
     // ---- this workgroup's range (wave-uniform): from the scan's table, or -- split == nullptr: a lattice sub-range, or
     // offsets that did not come with the scan -- found here by waves 0 and 1 (gridDim.x must be a power of two)
-    constexpr int NW = NS + 1 + NP, NT = 64 * NW;
-    int64_t e_lo, e_hi, Q0, Q1, p_all, off0;
-    int64_t e_stop;                                          // lattices from e_stop on are not written
-    int64_t e_lo_u = 0, e_hi_u = 0, Q0_u = 0;                // SCAN: the range before the capacity clamp
-    const int64_t* offs = SCAN ? offsets_w : offsets;
-    // SCAN: state of the workgroup's own scan of the counts (rounds of NT lattices from scan_e0 on, offsets so far scan_base)
-    __shared__ int64_t scan_wt[2 * NW];
-    __shared__ int64_t cut_e[3], cut_o[3];
-    int scan_par = 0;
-    int64_t scan_e0 = 0, scan_base = 0, T_lo = 0, T_hi = 0;
-    auto scan_round = [&](bool find_cuts, bool have_c = false, int c_pre = 0) {
-        // offsets of the lattices [scan_e0, scan_e0 + NT): for the caller and for this workgroup's producers.  The
-        // lattice whose perspectives straddle a target (offset < T <= offset + count) is the one in front of the cut.
-        const int64_t e = scan_e0 + (int64_t)threadIdx.x;
-        const int c = have_c ? c_pre : (e < N ? counts[e] : 0);
-        int64_t tot;
-        const int64_t o = scan_base + block_excl_scan64<NW>((int64_t)c, scan_wt, scan_par, wave, lane, tot);
-        if (e < N) {
-            offsets_w[e] = o;
-            if (counts_out) counts_out[e] = c;
-            if (e + 1 == N) offsets_w[N] = o + c;
-            if (find_cuts) {
-                if (o < T_lo && T_lo <= o + c) { cut_e[0] = e + 1; cut_o[0] = o + c; }
-                if (o < T_hi && T_hi <= o + c) { cut_e[1] = e + 1; cut_o[1] = o + c; }
-            }
-        }
-        scan_base += tot;
-        scan_e0 += NT;
-    };
-    if (SCAN) {
-        static_assert((SCAN_FUSE_MAX_PARTS + 1) * 2 <= (1 << RB_LOG), "level-1 sums must fit the ring");
-        int64_t* sc = reinterpret_cast<int64_t*>(S.bits);   // exclusive prefix of the level-1 sums, sc[nparts] = P
-        const int tid = (int)threadIdx.x;
-        const int nparts = (int)((N + PART_BLOCK - 1) / PART_BLOCK);
-        const int R = (nparts + NT - 1) / NT;                // <= 8 (the host checks nparts <= SCAN_FUSE_MAX_PARTS)
-        // the counts this workgroup will most likely need are fetched in the same round trip as the level-1 sums: equal
-        // shares of the perspectives are nearly equal shares of the lattices, so its targets lie in or next to the
-        // blocks blockIdx.x * nparts / G .. (blockIdx.x + 1) * nparts / G
-        int64_t g_blk = (int64_t)blockIdx.x * nparts / (int64_t)gridDim.x - 1;
-        g_blk = g_blk < 0 ? 0 : g_blk;
-        const int64_t s0 = g_blk * PART_BLOCK;
-        int c_spec[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int64_t e = s0 + (int64_t)r * NT + tid;
-            c_spec[r] = e < N ? counts[e] : 0;
-        }
-        int64_t v[8], mine = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = tid * R + k;
-            v[k] = (k < R && i < nparts) ? partial[i] : 0;
-            mine += v[k];
-        }
-        if (tid < 2) { cut_e[tid] = 0; cut_o[tid] = 0; }     // a target of 0: the cut is lattice 0
-        int64_t P;
-        int64_t run = block_excl_scan64<NW>(mine, scan_wt, scan_par, wave, lane, P);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = tid * R + k;
-            if (k < R && i < nparts) { sc[i] = run; run += v[k]; }
-        }
-        if (tid == 0) sc[nparts] = P;
-        __syncthreads();
-        const int LG = 31 - __clz((int)gridDim.x);
-        T_lo = (int64_t)(((uint64_t)P * (uint64_t)blockIdx.x) >> LG);
-        T_hi = (int64_t)(((uint64_t)P * (uint64_t)(blockIdx.x + 1)) >> LG);
-        // the 256-count blocks that hold the two targets (sc[js] < T <= sc[js + 1]); every wave for itself
-        int c_lo = 0, c_hi = 0;
-        for (int j = lane; j <= nparts; j += 64) { const int64_t x = sc[j]; c_lo += x < T_lo; c_hi += x < T_hi; }
-        const int js_lo = T_lo > 0 ? wave_sum32(c_lo) - 1 : 0, js_hi = T_hi > 0 ? wave_sum32(c_hi) - 1 : 0;
-        if (P > capacity && wave == 2) {
-            // the stack does not fit: the last lattice whose offset is <= capacity (= the number of lattices whose
-            // offset is < capacity + 1, less one) and that offset
-            const int64_t Tt = capacity + 1;
-            int c = 0;
-            for (int j = lane; j <= nparts; j += 64) c += sc[j] < Tt;
-            const int js = wave_sum32(c) - 1;
-            const int64_t eb = (int64_t)js * PART_BLOCK + 4 * lane;
-            int c4[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) c4[k] = eb + k < N ? counts[eb + k] : 0;
-            const int s4 = c4[0] + c4[1] + c4[2] + c4[3];
-            int inc = s4;
-#pragma unroll
-            for (int ofs = 1; ofs < 64; ofs <<= 1) {
-                const int t = __shfl_up(inc, ofs, 64);
-                if (lane >= ofs) inc += t;
-            }
-            int64_t oc = sc[js] + (int64_t)(inc - s4);
-            int nb = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { nb += (eb + k < N) && (oc < Tt); oc += c4[k]; }
-            const int nbt = wave_sum32(nb) - 1;              // 0 .. 255
-            int part = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) part += (4 * lane + k < nbt) ? c4[k] : 0;
-            const int64_t osum = sc[js] + (int64_t)wave_sum32(part);
-            if (lane == 0) { cut_e[2] = (int64_t)js * PART_BLOCK + nbt; cut_o[2] = osum; }
-        }
-        // the counts of those blocks (and a few lattices more, for the perspectives behind the range that its last
-        // lines need) in rounds of NT lattices -- one round for the usual 256 lattices per workgroup
-        int64_t w_end = ((int64_t)js_hi + 1) * PART_BLOCK + 64;
-        w_end = w_end < N ? w_end : N;
-        if (g_blk <= js_lo && w_end <= s0 + 2 * NT) {        // the guess holds: no second round trip
-            scan_e0 = s0;
-            scan_base = sc[g_blk];
-            scan_round(true, true, c_spec[0]);
-            if (scan_e0 < w_end) scan_round(true, true, c_spec[1]);
-        } else {
-            scan_e0 = (int64_t)js_lo * PART_BLOCK;
-            scan_base = sc[js_lo];
-            do scan_round(true); while (scan_e0 < w_end);
-        }
-        __syncthreads();
-        e_lo_u = cut_e[0]; e_hi_u = cut_e[1]; Q0_u = cut_o[0];
-        e_lo = e_lo_u; e_hi = e_hi_u; Q0 = Q0_u; Q1 = cut_o[1];
-        off0 = 0; p_all = P; e_stop = N;
-        if (P > capacity) {                                  // stack does not fit: only the lattices that fit whole are written
-            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, ERR_CAPACITY);
-            e_stop = cut_e[2]; p_all = cut_o[2];
-            if (e_lo > e_stop) { e_lo = e_stop; Q0 = p_all; }
-            if (e_hi > e_stop) { e_hi = e_stop; Q1 = p_all; }
-        }
+    int64_t e_lo, e_hi;
+    if (split) {
+        e_lo = split[blockIdx.x]; e_hi = split[blockIdx.x + 1];
     } else {
-        if (split) {
-            e_lo = split[blockIdx.x]; e_hi = split[blockIdx.x + 1];
-        } else {
-            __shared__ int64_t cut[2];
-            if (wave < 2) {
-                const int64_t e = find_cut(offsets, e_begin, e_end, (int)blockIdx.x + wave, 31 - __clz((int)gridDim.x), lane);
-                if (lane == 0) cut[wave] = e;
-            }
-            __syncthreads();
-            e_lo = cut[0]; e_hi = cut[1];
+        __shared__ int64_t cut[2];
+        if (wave < 2) {
+            const int64_t e = find_cut(offsets, e_begin, e_end, (int)blockIdx.x + wave, 31 - __clz((int)gridDim.x), lane);
+            if (lane == 0) cut[wave] = e;
         }
-        e_lo = e_lo < e_begin ? e_begin : (e_lo > e_end ? e_end : e_lo);       // whatever the table holds, stay inside the range
-        e_hi = e_hi < e_lo ? e_lo : (e_hi > e_end ? e_end : e_hi);
-        off0 = offsets[e_begin];
-        p_all = offsets[e_end] - off0;                       // perspectives of the whole stack
-        e_stop = e_end;
-        if (p_all > capacity) {                              // stack does not fit: only the lattices that fit whole are written
-            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, ERR_CAPACITY);
-            int64_t lo = e_begin, hi = e_end;                // largest e with offsets[e] - off0 <= capacity
-            while (lo < hi) {
-                const int64_t mid = (lo + hi + 1) >> 1;
-                if (offsets[mid] - off0 <= capacity) lo = mid; else hi = mid - 1;
-            }
-            e_stop = lo;
-            p_all = offsets[e_stop] - off0;
-            e_lo = e_lo < e_stop ? e_lo : e_stop;
-            e_hi = e_hi < e_stop ? e_hi : e_stop;
-        }
-        Q0 = offsets[e_lo] - off0; Q1 = offsets[e_hi] - off0;                  // perspective range [Q0, Q1)
+        __syncthreads();
+        e_lo = cut[0]; e_hi = cut[1];
     }
+    e_lo = e_lo < e_begin ? e_begin : (e_lo > e_end ? e_end : e_lo);       // whatever the table holds, stay inside the range
+    e_hi = e_hi < e_lo ? e_lo : (e_hi > e_end ? e_end : e_hi);
+    const int64_t off0 = offsets[e_begin];
+    int64_t p_all = offsets[e_end] - off0;                   // perspectives of the whole stack
+    int64_t e_stop = e_end;                                  // lattices from e_stop on are not written
+    if (p_all > capacity) {                                  // stack does not fit: only the lattices that fit whole are written
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, ERR_CAPACITY);
+        int64_t lo = e_begin, hi = e_end;                    // largest e with offsets[e] - off0 <= capacity
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (offsets[mid] - off0 <= capacity) lo = mid; else hi = mid - 1;
+        }
+        e_stop = lo;
+        p_all = offsets[e_stop] - off0;
+        e_lo = e_lo < e_stop ? e_lo : e_stop;
+        e_hi = e_hi < e_stop ? e_hi : e_stop;
+    }
+    const int64_t Q0 = offsets[e_lo] - off0, Q1 = offsets[e_hi] - off0;        // perspective range [Q0, Q1)
     const bool last = Q1 >= p_all;                           // no perspective behind this range
     const int64_t S0 = Q0 * NQ, S1 = Q1 * NQ;                // element range
     const int64_t org = S0 / LE * LE;                        // ring bit x <-> stack element org + x
@@ -368,17 +203,6 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
         if (!pos) need_extra = ne_s;
     }
     const bool has_stack = a1 > a0, has_pos = pos != nullptr && pa1 > pa0;
-    int64_t e_lim = e_stop;                                  // SCAN: the producers read offsets this workgroup has written itself
-    if (SCAN) {
-        // go on behind the blocks of the targets if this workgroup's lattices (the last workgroup also takes the lattices
-        // behind the last perspective) or the perspectives its last lines need reach further.  A neighbour writes the
-        // same values to the entries both need.
-        const int64_t e_w_hi = blockIdx.x + 1 == gridDim.x ? N : e_hi_u;
-        const int64_t QTs = (has_stack || has_pos) ? Q1 + need_extra : 0;
-        while (scan_e0 < N && (scan_e0 < e_w_hi || scan_base < QTs)) scan_round(false);
-        e_lim = scan_e0 < e_stop ? scan_e0 : e_stop;
-        __syncthreads();                                     // the stores above are visible to the whole workgroup
-    }
     if (!has_stack && !has_pos) return;                      // uniform over the workgroup
 
     // ---- ring and hand-off words
@@ -524,14 +348,14 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
     for (int64_t Lb = 0;; Lb += 64 * NP) {
         // the planes and offsets of this wave's next 64 lattices in one round of vector loads
         const int64_t e_l = e_lo + Lb + (int64_t)lane * NP + p;
-        const bool in = e_l < e_lim;
+        const bool in = e_l < e_stop;
         uint64_t vv[W], pp[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             vv[k] = in ? vp[(int64_t)k * N + e_l] : 0ull;
             pp[k] = in ? vp[((int64_t)W + k) * N + e_l] : 0ull;
         }
-        const int64_t oo = in ? offs[e_l] - off0 : (int64_t)0x7fffffffffffffffll;
+        const int64_t oo = in ? offsets[e_l] - off0 : (int64_t)0x7fffffffffffffffll;
         const uint64_t inmask = __ballot(in && oo < QT);     // offsets are monotone: a prefix of the lanes
         if (!inmask) break;
         const int cnt = __popcll(inmask);

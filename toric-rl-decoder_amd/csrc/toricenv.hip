@@ -151,31 +151,17 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
 // part of the stack.  Storer / producer waves per workgroup: the storers saturate a CU's store path with 2-4 waves
 // and the producers idle 80-90 % of the time for d >= 7 (profiles/r03_stack_write_ab.txt), but small lattices are
 // producer-bound (a d=3 lattice is 0.8 KB of output against a fixed set-up), so they get every wave that is left.
-// Scan folded into the write: what the count kernels left behind (counts, level-1 sums) goes in, offsets come out.
-struct ScanIn {
-    const int32_t* counts = nullptr;
-    const int64_t* partial = nullptr;
-    int64_t* offsets_w = nullptr;
-    int32_t* counts_out = nullptr;
-};
-
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, int* err, hipStream_t stream, int64_t first, int64_t count,
-                         const int32_t* split, const ScanIn* scan) {
+                         const int32_t* split) {
     constexpr int NS = D <= 5 ? 2 : 4, NP = D <= 5 ? 13 : (D >= 13 ? 7 : 11), CPW = 8;
     constexpr int RB = 14, RP = 12;                            // 64 KB bit ring, 16 KB position ring
     // a workgroup's part of the stack is addressed with 32-bit element offsets
     if ((double)count * (2.0 * D * D) * (2.0 * D * D) / SPLIT_MAX > 2.0e9)
         return fail(TQ_E_INVALID, "lattice range too large for one stack write (%lld lattices of d=%d)", (long long)count, D);
-    if (scan)
-        hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, false, true>), dim3(SPLIT_MAX), dim3(64 * (NS + 1 + NP)), 0,
-                           stream, vp, n, (const int64_t*)nullptr, (OutT*)out, pos, capacity, err, (int64_t)0, n, (const int32_t*)nullptr,
-                           (unsigned long long*)nullptr, scan->counts, scan->partial, scan->offsets_w, scan->counts_out);
-    else
-        hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP>), dim3(SPLIT_MAX), dim3(64 * (NS + 1 + NP)), 0, stream,
-                           vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split, (unsigned long long*)nullptr,
-                           (const int32_t*)nullptr, (const int64_t*)nullptr, (int64_t*)nullptr, (int32_t*)nullptr);
+    hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP>), dim3(SPLIT_MAX), dim3(64 * (NS + 1 + NP)), 0, stream,
+                       vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split, (unsigned long long*)nullptr);
     KCHECK();
     return TQ_OK;
 }
@@ -185,13 +171,13 @@ int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, 
 template <int D>
 int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                        int64_t capacity, int dtype, int* err, hipStream_t stream, int64_t first, int64_t count,
-                       const int32_t* split, const ScanIn* scan = nullptr) {
+                       const int32_t* split) {
     if (count == 0) return TQ_OK;
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, scan);
-        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, scan);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, scan);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, scan);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -569,37 +555,6 @@ int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count
     const int32_t* split = (first == 0 && count == h->n && offsets == h->split_for) ? h->split : nullptr;
 #define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream, first, count, \
         split)) return rc
-    DISPATCH_D(h->d, CALL)
-#undef CALL
-    return TQ_OK;
-}
-
-int tq_persp_count_write(tq_env* h, int32_t* counts, int64_t* offsets, void* out, int32_t* positions,
-                         int64_t capacity, int dtype, void* stream_) {
-    HANDLE(h);
-    if (!offsets || !out) return fail(TQ_E_INVALID, "offsets / out is NULL");
-    if (capacity < 0) return fail(TQ_E_INVALID, "negative capacity");
-    REQUIRE_ALIGNED16(offsets, "offsets");
-    REQUIRE_ALIGNED16(counts, "counts");
-    REQUIRE_ALIGNED16(out, "out");
-    REQUIRE_ALIGNED16(positions, "positions");
-    const int64_t nparts = ((int64_t)h->n + tq::PART_BLOCK - 1) / tq::PART_BLOCK;
-    if (nparts > tq::SCAN_FUSE_MAX_PARTS) {                  // more level-1 sums than the write's prologue holds: two launches
-        if (int rc = tq_persp_count(h, counts, offsets, stream_)) return rc;
-        return tq_persp_write(h, offsets, out, positions, capacity, dtype, stream_);
-    }
-    if (!h->partial_valid) {
-        hipLaunchKernelGGL(tq::k_scan_partials, dim3((unsigned)nparts), dim3(256), 0, stream, (const int32_t*)h->counts, h->partial,
-                           (int64_t)h->n);
-        KCHECK();
-        h->partial_valid = true;
-    }
-    h->split_for = nullptr;                                  // the table of an earlier tq_persp_count no longer describes `offsets`
-    ScanIn scan;
-    scan.counts = h->counts; scan.partial = h->partial; scan.offsets_w = offsets; scan.counts_out = counts;
-    const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, nullptr, out, positions, capacity, dtype, h->err, stream, 0, h->n, \
-        nullptr, &scan)) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;

@@ -411,28 +411,8 @@ class EnvSet:
                        _DTYPES[out.dtype])
         self._positions = positions
 
-    def countAndWritePerspectives(self, out, positions=None, offsets=None):
-        """perspectiveCounts + writePerspectives in ONE launch (tq_persp_count_write) for a caller that already owns
-        the stack buffer ``out``: the scan runs in the prologue of the write kernel.  ``offsets``: optional
-        caller-owned int64[N+1] tensor that receives the scan.  -> (counts, offsets); no synchronisation.  A stack that
-        does not fit ``out`` latches TQ_E_CAPACITY (check())."""
-        if out.dtype not in _DTYPES or not out.is_contiguous():
-            raise ValueError("out must be a contiguous float32/float16/bfloat16/uint8 tensor")
-        nq = 2 * self.size * self.size
-        cap = out.numel() // nq
-        if positions is not None and (positions.dtype != torch.int32 or positions.numel() < 3 * cap):
-            raise ValueError("positions must be int32 with at least 3*capacity elements")
-        if offsets is not None:
-            if offsets.dtype != torch.int64 or offsets.numel() != self.no_envs + 1 or not offsets.is_contiguous():
-                raise ValueError("offsets must be a contiguous int64 tensor of no_envs + 1 elements")
-            self._offsets = offsets
-        self._call(self._L.tq_persp_count_write, _ptr(self._counts), _ptr(self._offsets), _ptr(out), _ptr(positions), cap,
-                   _DTYPES[out.dtype])
-        self._positions = positions
-        return self._counts, self._offsets
-
     def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=3,
-                        kinds=("torch", "chunked"), good_enough=0.86, park=False, first=0, count=None):
+                        kinds=("torch", "chunked"), good_enough=0.83, park=False, first=0, count=None):
         """Set-up helper: allocate ``candidates`` stack buffers (``capacity`` perspectives each, default the worst
         case no_envs * 2*d*d), time the stack write of the CURRENT lattices on each of them and keep the fastest.
         Where a buffer lies in HBM changes the rate of ANY write stream into it by up to 20 % on MI355X (a plain fill
@@ -442,8 +422,8 @@ class EnvSet:
         helper), "chunked" = alloc_stack (2 MiB physical chunks: 6.5-6.7 TB/s against 5.2-5.5 for plain allocations
         in most runs).  -> (stack tensor (capacity,2,d,d),
         report dict with the ms and kind of every candidate).  The probe stops early once a candidate takes less than
-        ``good_enough`` x the time of candidate 0 (the two kinds of placement are ~20 % apart, nothing lies in
-        between).  ``park``: keep the rejected candidates allocated until releaseParked() / close() instead of
+        ``good_enough`` x the time of candidate 0 (well-placed buffers take 0.79-0.83 x the time of a plain
+        allocation; on some boxes candidates lie anywhere in between, so a looser threshold stops at a mediocre one).  ``park``: keep the rejected candidates allocated until releaseParked() / close() instead of
         freeing them here -- the driver wipes freed device memory in the background, tens of GB of it take HBM
         bandwidth away from whatever runs in the next tens of milliseconds (a benchmark's timed region, say).
         ``first`` / ``count``: time the write of that lattice range only (a consumer that walks the batch in ranges

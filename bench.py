@@ -87,8 +87,11 @@ def parse(argv=None):
     ap.add_argument("--stack-candidates", type=int, default=12,
                     help="stack buffers to allocate at set-up; the one the write kernel is fastest on is kept, the others are "
                          "freed (where a buffer lies in HBM changes the write rate by up to 20 %% on this part: "
-                         "profiles/r03_stack_write_ab.txt; the probe stops at the first candidate that is 14 %% faster than the "
-                         "first).  1 = take the first allocation as it comes")
+                         "profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")
+    ap.add_argument("--stack-good-enough", type=float, default=0.80,
+                    help="the probe stops early at a candidate whose write takes less than this fraction of candidate 0's "
+                         "(well-placed buffers take 0.79-0.83 of a plain allocation's time and differ by ~2 %% among "
+                         "themselves: the default tries nearly always all candidates, ~1 s of set-up)")
     ap.add_argument("--stack-kinds", default="torch,chunked",
                     help="where the candidates come from (first entry: candidate 0, the rest cyclically for the others): torch = "
                          "torch.empty, chunked = T.alloc_stack (2 MiB physical "
@@ -197,7 +200,7 @@ class Shard:
 
 
 def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False, candidates=1,
-                    kinds=("torch", "chunked"), event_every=4):
+                    kinds=("torch", "chunked"), event_every=4, good_enough=0.80):
     """The same pass over a batch of `n` lattices on the current stream, no collective: burn-in, `warm` untimed
     and `steps` timed steps.  -> (seconds, perspectives in the timed steps, per-step stack-write milliseconds
     from HIP events or None).  Used at N=1 for the extra legs of the line: one GPU on the per-GPU shape of the
@@ -223,10 +226,10 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
         del stack
         torch.cuda.empty_cache()
         if chunks == 1:
-            stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions, kinds=kinds, park=True)
+            stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions, kinds=kinds, park=True, good_enough=good_enough)
         else:                                                        # the small buffer of the range-by-range consumer, probed with the first range
             stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, capacity=(n // chunks) * nq, positions=positions, kinds=kinds,
-                                                park=True, first=0, count=n // chunks)
+                                                park=True, first=0, count=n // chunks, good_enough=good_enough)
 
     def step(t):
         off = offs[t][:n + 1]
@@ -510,7 +513,7 @@ def main():
         torch.cuda.empty_cache()
         # rejected candidates stay parked until the timed region is over: the driver wipes freed memory in the background
         sh0.stack, probe = sh0.envs.pickStackBuffer(args.stack_candidates, dtype=tdtype, capacity=cap, positions=sh0.positions, kinds=kinds,
-                                                    park=True)
+                                                    park=True, good_enough=args.stack_good_enough)
         probe["note"] = ("set-up, untimed (EnvSet.pickStackBuffer): 3 stack writes timed on each candidate buffer, the fastest kept, "
                          "the others freed; candidate 0 is the allocation a caller gets by default (torch.empty), 'chunked' is "
                          "T.alloc_stack = tq_stack_alloc (2 MiB physical chunks)")
@@ -592,7 +595,8 @@ def main():
     if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore" and not args.no_shard_leg:
         k2, w2 = max(8, min(K, 40)), 8
         print("[bench] configs[4] shard leg (131072 lattices on this GPU) ...", file=sys.stderr, flush=True)
-        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates)
+        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates,
+                                     good_enough=args.stack_good_enough)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
                      "perspectives_per_sec": P2 / dt2, "stack_buffer_probe": time_plain_loop.last_probe,
                      "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
@@ -610,7 +614,7 @@ def main():
         for name, ch in (("one_shot", 1), ("chunks_4", 4)):
             print("[bench] configs[3] leg (65536 lattices, d=9, p=0.15), %s ..." % name, file=sys.stderr, flush=True)
             dt3, P3, ev3 = time_plain_loop(T, torch, env3, n3, d3, args.seed, 0, tdtype, flush, device, k3, w3, chunks=ch, events=True,
-                                           candidates=args.stack_candidates, event_every=args.event_every)
+                                           candidates=args.stack_candidates, event_every=args.event_every, good_enough=args.stack_good_enough)
             alg3 = time_plain_loop.last_p_bracketed * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
             c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
                             "stack_buffer_probe": time_plain_loop.last_probe,

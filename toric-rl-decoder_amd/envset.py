@@ -466,7 +466,11 @@ class EnvSet:
         del keep, c
         if not park:
             torch.cuda.empty_cache()
-        return best, {"candidates": len(ms), "write_ms": ms, "chosen": int(np.argmin(ms)), "kinds": used}
+        report = {"candidates": len(ms), "write_ms": ms, "chosen": int(np.argmin(ms)), "kinds": used}
+        if len(ms) > 2 and min(ms) > 0.9 * ms[0]:
+            report["uniform"] = ("no candidate writes more than 10 % faster than candidate 0: on some boxes every buffer -- and "
+                                 "every write stream, hipMemset included -- runs at one rate (profiles/r03_stack_write_ab.txt)")
+        return best, report
 
     def releaseParked(self):
         """Free the candidates pickStackBuffer(park=True) kept."""

@@ -84,14 +84,13 @@ def parse(argv=None):
                          "its own PCIe link (0 = auto: 2 from 8 ranks on, where one Gen5 x16 link no longer carries "
                          "the ~63 GB/s of packed records; 1 below)")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
-    ap.add_argument("--stack-candidates", type=int, default=12,
+    ap.add_argument("--stack-candidates", type=int, default=3,
                     help="stack buffers to allocate at set-up; the one the write kernel is fastest on is kept, the others are "
-                         "freed (where a buffer lies in HBM changes the write rate by up to 20 %% on this part: "
-                         "profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")
-    ap.add_argument("--stack-good-enough", type=float, default=0.80,
+                         "freed (the write rate depends on the buffer: 5.2-5.5 TB/s into a plain allocation, 7.0-7.2 into a "
+                         "tq_stack_alloc buffer, profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")
+    ap.add_argument("--stack-good-enough", type=float, default=0.70,
                     help="the probe stops early at a candidate whose write takes less than this fraction of candidate 0's "
-                         "(well-placed buffers take 0.79-0.83 of a plain allocation's time and differ by ~2 %% among "
-                         "themselves: the default tries nearly always all candidates, ~1 s of set-up)")
+                         "(tq_stack_alloc buffers take 0.75-0.80 of a plain allocation's time: the default tries all candidates)")
     ap.add_argument("--stack-kinds", default="torch,chunked",
                     help="where the candidates come from (first entry: candidate 0, the rest cyclically for the others): torch = "
                          "torch.empty, chunked = T.alloc_stack (2 MiB physical "

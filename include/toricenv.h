@@ -89,10 +89,16 @@ int tq_set_min_qubit_errors(tq_env* h, int n_errors);
 int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_final, double p_delta);
 
 /* Set-up helper for the caller-owned stack buffer (np.concatenate's result, numba/util_actor.py:37-39, written every
- * step): device memory of at least `bytes` bytes backed by 2 MiB physical chunks (HIP virtual memory API).  Where a
- * buffer lies in HBM changes the rate of every write stream into it by up to 20 % on MI355X; buffers made of 2 MiB
- * chunks were the fast kind in nearly every run (profiles/r03_stack_write_ab.txt).  Allocates and synchronises; any
- * other device allocation works as `out` of tq_persp_write just as well. */
+ * step).  On MI355X the rate of every write stream into a freshly mapped buffer -- the stack write, a plain fill,
+ * hipMemset -- is 5.3-6.5 TB/s depending on the box and the allocation (plain hipMalloc / torch.empty buffers are among
+ * the slow ones in a PyTorch process).  tq_stack_alloc returns device memory of at least `bytes` bytes made of 2 MiB
+ * physical chunks (HIP virtual memory API) that has been "walked in": mapped at 17 virtual addresses (128 MiB or 1/16 of
+ * the buffer apart, whichever is more) inside a window reserved for it and written once (hipMemset, zeros) at each;
+ * after that the last address -- the one returned -- writes at 7.0-7.2 TB/s on slow and fast boxes alike and stays
+ * that fast (tools/placement_bench.hip, tools/walk_probe.py, profiles/r03_stack_write_ab.txt section 12: mapping
+ * without writing, writing repeatedly at one address, or two addresses in turn do nothing).  Costs ~0.2 s per GB;
+ * allocates, maps and synchronises.  Any other device allocation
+ * works as `out` of tq_persp_write just as well. */
 int tq_stack_alloc(int device, uint64_t bytes, void** out);
 int tq_stack_free(void* ptr);
 

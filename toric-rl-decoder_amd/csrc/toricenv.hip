@@ -243,9 +243,61 @@ int tq_version(void) { return TQ_VERSION; }
 
 // ---- stack buffers backed by 2 MiB physical chunks (HIP virtual memory API)
 namespace {
-struct ChunkedAlloc { void* va; size_t bytes; int device; };
+// A tq_stack_alloc buffer: 2 MiB physical chunks behind a virtual address window of its own, "walked in".
+// Measured on MI355X (tools/placement_bench.hip, profiles/r03_stack_write_ab.txt section 12): the rate of every write
+// stream into a freshly mapped buffer -- the stack write, hipMemset -- is 5.3-6.5 TB/s depending on the box; after the
+// same physical chunks have been mapped at a series of SHIFTED virtual addresses and written once at each of them, the
+// last address writes at 7.0-7.2 TB/s, and stays that fast.  Mapping without writing, writing repeatedly at one
+// address, or going back and forth between two addresses does nothing; the walk has to cover about the buffer's own
+// size (a 6.4 GiB buffer: 16 x 128 MiB is not enough, 16 x 256 MiB and 8 x 512 MiB are) in 8 or more steps.
+constexpr int STACK_WALK_STEPS = 16;
+constexpr size_t STACK_WALK_MIN_SHIFT = (size_t)128 << 20;
+struct ChunkedAlloc {
+    char* window = nullptr;
+    size_t window_bytes = 0, bytes = 0, chunk = 0, offset = 0;
+    int device = 0;
+    std::vector<hipMemGenericAllocationHandle_t> h;
+    char* va() const { return window + offset; }
+};
 std::mutex g_alloc_mu;
-std::vector<ChunkedAlloc> g_allocs;
+std::vector<ChunkedAlloc*> g_allocs;
+
+// maps every chunk of `a` at window + offset; on failure nothing stays mapped there
+hipError_t chunked_map(ChunkedAlloc* a, size_t offset) {
+    char* va = a->window + offset;
+    size_t mapped = 0;
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < a->h.size() && e == hipSuccess; ++i) {
+        e = hipMemMap(va + i * a->chunk, a->chunk, 0, a->h[i], 0);
+        if (e == hipSuccess) ++mapped;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = a->device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, a->bytes, &acc, 1);
+    }
+    if (e != hipSuccess)
+        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(va + i * a->chunk, a->chunk);
+    if (e == hipSuccess) a->offset = offset;
+    return e;
+}
+// every chunk was mapped by a hipMemMap of its own and is unmapped the same way
+hipError_t chunked_unmap(ChunkedAlloc* a, size_t count) {
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < count; ++i) {
+        const hipError_t x = hipMemUnmap(a->va() + i * a->chunk, a->chunk);
+        if (x != hipSuccess) e = x;
+    }
+    return e;
+}
+void chunked_release(ChunkedAlloc* a, bool is_mapped) {
+    if (is_mapped) (void)chunked_unmap(a, a->h.size());
+    for (auto& x : a->h) (void)hipMemRelease(x);
+    if (a->window) (void)hipMemAddressFree(a->window, a->window_bytes);
+    delete a;
+}
 }  // namespace
 
 int tq_stack_alloc(int device, uint64_t bytes, void** out) {
@@ -254,58 +306,74 @@ int tq_stack_alloc(int device, uint64_t bytes, void** out) {
     if (bytes == 0) return fail(TQ_E_INVALID, "bytes must be > 0");
     DeviceGuard guard;
     if (int rc = guard.enter_device(device)) return rc;
+    // TORIC_STACK_WALK="steps,shift MiB" overrides the walk (experiments; "0,0" = map once)
+    int steps = STACK_WALK_STEPS;
+    size_t shift = ((size_t)bytes + STACK_WALK_STEPS - 1) / STACK_WALK_STEPS;     // the walk covers the buffer's own size
+    if (shift < STACK_WALK_MIN_SHIFT) shift = STACK_WALK_MIN_SHIFT;
+    if (const char* w = getenv("TORIC_STACK_WALK")) {
+        int s_ = 0, m_ = 0;
+        if (sscanf(w, "%d,%d", &s_, &m_) == 2 && s_ >= 0 && s_ <= 256 && m_ >= 0 && m_ <= 65536) { steps = s_; shift = (size_t)m_ << 20; }
+    }
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = device;
     size_t gran = 0;
     HIPCHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-    size_t chunk = (size_t)2 << 20;
-    chunk = (chunk + gran - 1) / gran * gran;
-    const size_t n = ((size_t)bytes + chunk - 1) / chunk;
-    void* va = nullptr;
-    HIPCHECK(hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0));
-    size_t mapped = 0;
-    hipError_t e = hipSuccess;
+    ChunkedAlloc* a = new (std::nothrow) ChunkedAlloc();
+    if (!a) return fail(TQ_E_HIP, "out of host memory");
+    a->chunk = (((size_t)2 << 20) + gran - 1) / gran * gran;
+    shift = (shift + a->chunk - 1) / a->chunk * a->chunk;
+    const size_t n = ((size_t)bytes + a->chunk - 1) / a->chunk;
+    a->bytes = n * a->chunk;
+    a->device = device;
+    a->window_bytes = a->bytes + (size_t)steps * shift;
+    hipError_t e = hipMemAddressReserve((void**)&a->window, a->window_bytes, 0, nullptr, 0);
+    if (e != hipSuccess) {
+        a->window = nullptr;
+        chunked_release(a, false);
+        return fail(TQ_E_HIP, "reserving %zu bytes of virtual addresses failed: %s", a->window_bytes, hipGetErrorString(e));
+    }
+    a->h.reserve(n);
     for (size_t i = 0; i < n && e == hipSuccess; ++i) {
         hipMemGenericAllocationHandle_t hnd;
-        e = hipMemCreate(&hnd, chunk, &prop, 0);
-        if (e != hipSuccess) break;
-        e = hipMemMap((char*)va + i * chunk, chunk, 0, hnd, 0);
-        (void)hipMemRelease(hnd);                            // the mapping keeps the memory alive
-        if (e == hipSuccess) ++mapped;
+        e = hipMemCreate(&hnd, a->chunk, &prop, 0);
+        if (e == hipSuccess) a->h.push_back(hnd);
     }
-    if (e == hipSuccess) {
-        hipMemAccessDesc acc = {};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        e = hipMemSetAccess(va, n * chunk, &acc, 1);
+    // the walk: map, write once, unmap, one shift further; the buffer stays at the last address
+    for (int k = 0; k <= steps && e == hipSuccess; ++k) {
+        e = chunked_map(a, (size_t)k * shift);
+        if (e != hipSuccess) break;
+        if (steps > 0) {
+            e = hipMemsetAsync(a->va(), 0, a->bytes, nullptr);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        }
+        if (e == hipSuccess && k < steps) e = chunked_unmap(a, a->h.size());
+        else if (e != hipSuccess) (void)chunked_unmap(a, a->h.size());
     }
     if (e != hipSuccess) {
-        if (mapped) (void)hipMemUnmap(va, mapped * chunk);
-        (void)hipMemAddressFree(va, n * chunk);
+        chunked_release(a, false);
         return fail(TQ_E_HIP, "chunked allocation of %llu bytes failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
     }
     std::lock_guard<std::mutex> lock(g_alloc_mu);
-    g_allocs.push_back(ChunkedAlloc{va, n * chunk, device});
-    *out = va;
+    g_allocs.push_back(a);
+    *out = a->va();
     return TQ_OK;
 }
 
 int tq_stack_free(void* ptr) {
     if (!ptr) return TQ_OK;
-    ChunkedAlloc a{nullptr, 0, 0};
+    ChunkedAlloc* a = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_alloc_mu);
         for (size_t i = 0; i < g_allocs.size(); ++i)
-            if (g_allocs[i].va == ptr) { a = g_allocs[i]; g_allocs[i] = g_allocs.back(); g_allocs.pop_back(); break; }
+            if (g_allocs[i]->va() == ptr) { a = g_allocs[i]; g_allocs[i] = g_allocs.back(); g_allocs.pop_back(); break; }
     }
-    if (!a.va) return fail(TQ_E_INVALID, "pointer did not come from tq_stack_alloc");
+    if (!a) return fail(TQ_E_INVALID, "pointer did not come from tq_stack_alloc");
     DeviceGuard guard;
-    if (int rc = guard.enter_device(a.device)) return rc;
-    HIPCHECK(hipDeviceSynchronize());
-    HIPCHECK(hipMemUnmap(a.va, a.bytes));
-    HIPCHECK(hipMemAddressFree(a.va, a.bytes));
+    if (int rc = guard.enter_device(a->device)) { std::lock_guard<std::mutex> lock(g_alloc_mu); g_allocs.push_back(a); return rc; }
+    (void)hipDeviceSynchronize();
+    chunked_release(a, true);
     return TQ_OK;
 }
 const char* tq_last_error(void) { return g_err; }

@@ -803,5 +803,26 @@ def test_chunked_stack_buffer_and_placement_probe(T):
     L = T.load()
     assert L.tq_stack_free(C.c_void_p(ref.data_ptr())) == -1 and b"tq_stack_alloc" in L.tq_last_error()   # not one of ours
     assert L.tq_stack_free(None) == 0
+    # the walk leaves nothing behind: allocate-and-free cycles return the memory, failures too
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(4):
+        w = T.alloc_walked((300 << 20,), torch.uint8, gpu.device)      # 300 MiB: walked over 16 x 128 MiB of addresses
+        assert w.data_ptr() % (2 << 20) == 0 and bool((w == 0).all())             # zero-filled
+        w[::4097] = 7
+        assert int(w[::4097].sum().item()) == 7 * len(w[::4097])
+        del w
+    tiny = T.alloc_walked((3, 5), torch.int32, gpu.device)
+    tiny[:] = 5
+    assert int(tiny.sum().item()) == 75
+    del tiny
+    p_ = C.c_void_p(None)
+    assert L.tq_stack_alloc(0, 0, C.byref(p_)) == -1                    # bytes == 0
+    assert L.tq_stack_alloc(0, 1 << 46, C.byref(p_)) == -2 and not p_.value     # 64 TiB: fails, cleans up
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free1 - free0) < (256 << 20), (free0, free1)
     del chk, best
     gpu.close()

@@ -330,9 +330,10 @@ int tq_stack_alloc(int device, uint64_t bytes, void** out) {
     a->window_bytes = a->bytes + (size_t)steps * shift;
     hipError_t e = hipMemAddressReserve((void**)&a->window, a->window_bytes, 0, nullptr, 0);
     if (e != hipSuccess) {
+        const size_t wanted = a->window_bytes;
         a->window = nullptr;
         chunked_release(a, false);
-        return fail(TQ_E_HIP, "reserving %zu bytes of virtual addresses failed: %s", a->window_bytes, hipGetErrorString(e));
+        return fail(TQ_E_HIP, "reserving %zu bytes of virtual addresses failed: %s", wanted, hipGetErrorString(e));
     }
     a->h.reserve(n);
     for (size_t i = 0; i < n && e == hipSuccess; ++i) {

@@ -179,6 +179,46 @@ def cpu_baseline(d, p, seed, budget_s):
     v1, pps1, steps1, dt1 = timed(512, 1, 0.2 * budget_s)
     out["one_core"] = {"value": v1, "cores": 1, "perspectives_per_sec": pps1,
                        "sample": f"512 lattices x {steps1} steps, 1 thread, {dt1:.1f} s"}
+    # the same C-ABI on host memory (oracle/host_twin.cpp over the product's csrc/lattice.hpp: SURVEY 8b / 8d "C++ host
+    # backend ... on 1 core and on all cores"): counts -> f32 stack + positions -> fused step with transition records
+    try:
+        from oracle import host_twin as H
+
+        def twin_timed(n, nthreads, budget):
+            L.tor_set_threads(nthreads)                           # one OpenMP runtime serves both libraries
+            tw = H.HostEnvSet(d, n, p_error=p, seed=seed)
+            tw.reset_all()
+            nq = 2 * d * d
+            cap = n * nq
+            stack, pos = np.empty((cap, 2, d, d), np.float32), np.empty((cap, 3), np.int32)
+            blk, bc = tw.new_block(steps=8)
+
+            def step(t):
+                off = tw.perspectives(out=stack, positions=pos, capacity=cap)[3]
+                tw.actor_step(None, block=blk, block_cap=bc, slot=t % 8, want_actions=False)
+                return int(off[-1])
+            for t in range(2):
+                step(t)
+            t0 = time.perf_counter()
+            step(2)
+            probe = time.perf_counter() - t0
+            steps = int(max(3, min(2000, budget / max(probe, 1e-6))))
+            t0 = time.perf_counter()
+            P = sum(step(t) for t in range(steps))
+            dt = time.perf_counter() - t0
+            tw.check()
+            tw.close()
+            return n * steps / dt, P / dt, steps, dt
+
+        vt, ppt, st_, dtt = twin_timed(4096, threads, 0.15 * budget_s)
+        v1t, pp1t, s1t, dt1t = twin_timed(512, 1, 0.1 * budget_s)
+        out["host_twin"] = {"value": vt, "unit": "env-steps/s", "cores": int(threads), "kind": "port", "perspectives_per_sec": ppt,
+                            "sample": f"4096 lattices x {st_} steps, d={d}, p={p}: the C-ABI's hot path on host memory "
+                                      f"(oracle/host_twin.cpp, bit-plane algebra of csrc/lattice.hpp, OpenMP, {threads} threads), {dtt:.1f} s",
+                            "one_core": {"value": v1t, "cores": 1, "perspectives_per_sec": pp1t,
+                                         "sample": f"512 lattices x {s1t} steps, 1 thread, {dt1t:.1f} s"}}
+    except Exception as e:                                        # the twin is an extra; the baseline above stands without it
+        out["host_twin"] = {"error": repr(e)}
     L.tor_set_threads(threads)
     from oracle import toric_oracle as O
     n_ref, s_ref = (256, 20) if budget_s >= 5 else (32, 2)    # full SURVEY sample only with a real budget

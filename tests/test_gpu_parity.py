@@ -826,3 +826,39 @@ def test_chunked_stack_buffer_and_placement_probe(T):
     assert abs(free1 - free0) < (256 << 20), (free0, free1)
     del chk, best
     gpu.close()
+
+
+@pytest.mark.parametrize("d,strategy", [(5, "linear"), (7, "random"), (13, "fixed")])
+def test_hip_equals_the_host_twin_call_for_call(T, d, strategy):
+    """The same ABI calls on the GPU (libtoricenv.so) and on host memory (oracle/host_twin.cpp, the twin built on the
+    product's csrc/lattice.hpp): states, qubits, counters, counts, offsets, f32 stack, positions and the packed
+    transition block BYTE FOR BYTE after 24 fused steps with the p_error schedule."""
+    from oracle import host_twin as H
+    n, steps, max_steps = 3000, 24, 7
+    p0 = P_OF[d]
+    gpu, _ = make_pair(T, d, n, p=p0, seed=91, first=4000, numpy_io=False, max_steps_per_episode=max_steps)
+    tw = H.HostEnvSet(d, n, p_error=p0, seed=91, first_env_id=4000, max_steps_per_episode=max_steps)
+    gpu.set_perror_schedule(strategy, 0.04, 0.22, 0.02)
+    tw.set_perror_schedule(strategy, 0.04, 0.22, 0.02)
+    assert np.array_equal(gpu.resetAll().cpu().numpy(), tw.reset_all())
+    gblk = gpu.newTransitionBlock(steps=steps)
+    hblk, hcap = tw.new_block(steps=steps)
+    for t in range(steps):
+        per, pos, cnt = gpu.generatePerspective()
+        hper, hpos, hcnt, hoff = tw.perspectives(np.float32)
+        assert np.array_equal(cnt.cpu().numpy(), hcnt) and np.array_equal(gpu._offsets.cpu().numpy(), hoff)
+        assert np.array_equal(per.cpu().numpy(), hper) and np.array_equal(pos.cpu().numpy(), hpos)
+        act, rew, term = gpu.actorStep(None, block=gblk, slot=t)
+        hact, hrew, hterm = tw.actor_step(None, block=hblk, block_cap=hcap, slot=t)
+        assert np.array_equal(act.cpu().numpy(), hact) and np.array_equal(rew.cpu().numpy(), hrew)
+        assert np.array_equal(term.cpu().numpy(), hterm)
+    assert np.array_equal(gpu.getStates().cpu().numpy(), tw.states()) and np.array_equal(gpu.getQubits().cpu().numpy(), tw.qubits())
+    ep, st = gpu.getCounters()
+    hep, hst = tw.counters()
+    assert np.array_equal(ep.cpu().numpy().astype(np.uint32), hep) and np.array_equal(st.cpu().numpy().astype(np.uint32), hst)
+    assert int(hep.max()) >= 3
+    gpu.check()
+    tw.check()
+    assert np.array_equal(gblk.buf.cpu().numpy()[:hblk.size], hblk)        # priorities: zeros on both sides
+    gpu.close()
+    tw.close()

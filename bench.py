@@ -84,13 +84,14 @@ def parse(argv=None):
                          "its own PCIe link (0 = auto: 2 from 8 ranks on, where one Gen5 x16 link no longer carries "
                          "the ~63 GB/s of packed records; 1 below)")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
-    ap.add_argument("--stack-candidates", type=int, default=3,
+    ap.add_argument("--stack-candidates", type=int, default=12,
                     help="stack buffers to allocate at set-up; the one the write kernel is fastest on is kept, the others are "
-                         "freed (the write rate depends on the buffer: 5.2-5.5 TB/s into a plain allocation, 7.0-7.2 into a "
-                         "tq_stack_alloc buffer, profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")
-    ap.add_argument("--stack-good-enough", type=float, default=0.70,
+                         "freed (the write rate depends on the buffer: 5.1-5.5 TB/s into a plain allocation, 6.5-6.8 into most "
+                         "tq_stack_alloc buffers on most boxes, profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")
+    ap.add_argument("--stack-good-enough", type=float, default=0.80,
                     help="the probe stops early at a candidate whose write takes less than this fraction of candidate 0's "
-                         "(tq_stack_alloc buffers take 0.75-0.80 of a plain allocation's time: the default tries all candidates)")
+                         "(well-placed buffers take 0.79-0.83 of a plain allocation's time and differ by ~2 %% among themselves: "
+                         "the default tries nearly always all candidates, ~1 s of set-up)")
     ap.add_argument("--stack-kinds", default="torch,chunked",
                     help="where the candidates come from (first entry: candidate 0, the rest cyclically for the others): torch = "
                          "torch.empty, chunked = T.alloc_stack (2 MiB physical "
@@ -297,6 +298,20 @@ def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, ste
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     P = float(offs[warm:, n].sum().item())
+    # the timed buffer holds the right bytes (see main): whole batch, or the last range of the range-by-range consumer
+    off_v = offs[0][:n + 1]
+    envs.perspectiveCounts(off_v)
+    first_v, count_v = (0, n) if chunks == 1 else ((chunks - 1) * (n // chunks), n // chunks)
+    Pv = int((off_v[first_v + count_v] - off_v[first_v]).item())
+    ref_s = torch.empty((Pv, 2, d, d), dtype=tdtype, device=device)
+    ref_p = torch.empty((Pv, 3), dtype=torch.int32, device=device)
+    envs.writePerspectives(ref_s, ref_p, off_v, first=first_v, count=count_v)
+    stack.view(torch.uint8).fill_(0x5A)
+    envs.writePerspectives(stack, positions, off_v, first=first_v, count=count_v)
+    torch.cuda.synchronize(device)
+    wrong = int((stack[:Pv].view(torch.uint8) != ref_s.view(torch.uint8)).sum().item()) + int((positions[:Pv] != ref_p).sum().item())
+    time_plain_loop.last_verified = {"ok": wrong == 0, "wrong_bytes": wrong, "perspectives": Pv}
+    del ref_s, ref_p
     time_plain_loop.last_p_bracketed = float(offs[warm::every, n].double().mean().item())   # per step, of the steps the events bracket
     envs.check()
     envs.close()                                                    # frees the parked candidates of the probe as well ...
@@ -619,6 +634,29 @@ def main():
     if use_events:
         ev_ms = np.array([[a.elapsed_time(b) for a, b in sh.ev] for sh in shards])         # (S, K) launch durations
 
+    # ---- the buffer that was timed holds the right bytes: the stack of the current lattices written into it and into a
+    # fresh torch.empty buffer, compared element for element (untimed).  Not a formality: a buffer reached through stale
+    # address translations takes writes at 7 TB/s and is wrong in 70 % of its elements (profiles/r03_stack_write_ab.txt 12).
+    verified = None
+    if S == 1 and CH == 1 and graph is None:
+        sh0 = shards[0]
+        off_v = sh0.offs[-1][:ns + 1]
+        sh0.envs.perspectiveCounts(off_v)
+        Pv = int(off_v[-1].item())
+        ref_s = torch.empty((Pv, 2, d, d), dtype=tdtype, device=device)
+        ref_p = torch.empty((Pv, 3), dtype=torch.int32, device=device)
+        sh0.envs.writePerspectives(ref_s, ref_p, off_v)
+        sh0.stack.view(torch.uint8).fill_(0x5A)
+        sh0.envs.writePerspectives(sh0.stack, sh0.positions, off_v)
+        torch.cuda.synchronize(device)
+        wrong = int((sh0.stack[:Pv].view(torch.uint8) != ref_s.view(torch.uint8)).sum().item()) + int((sh0.positions[:Pv] != ref_p).sum().item())
+        verified = {"ok": wrong == 0, "wrong_bytes": wrong, "perspectives": Pv,
+                    "how": "after the timed region: stack + positions of the current lattices written into the timed buffer and into "
+                           "a fresh torch.empty buffer, compared byte for byte"}
+        del ref_s, ref_p
+        if wrong:
+            print("[bench] THE TIMED STACK BUFFER HOLDS WRONG BYTES (%d): the numbers of this run are void" % wrong, file=sys.stderr, flush=True)
+
     # ---- N>1 with host delivery: the same region again with the ring kept in rank 0's HBM
     hbm_ring = None
     if host_delivery and graph is None:
@@ -638,6 +676,7 @@ def main():
                                      good_enough=args.stack_good_enough)
         shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
                      "perspectives_per_sec": P2 / dt2, "stack_buffer_probe": time_plain_loop.last_probe,
+                     "stack_verified": time_plain_loop.last_verified,
                      "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
                              "no collective: the like-for-like base of the scaling curve"}
 
@@ -656,7 +695,7 @@ def main():
                                            candidates=args.stack_candidates, event_every=args.event_every, good_enough=args.stack_good_enough)
             alg3 = time_plain_loop.last_p_bracketed * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
             c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
-                            "stack_buffer_probe": time_plain_loop.last_probe,
+                            "stack_buffer_probe": time_plain_loop.last_probe, "stack_verified": time_plain_loop.last_verified,
                             "perspectives_per_sec": P3 / dt3, "perspectives_per_lattice": P3 / (k3 * n3),
                             "roofline": {"bound": "hbm", "kernel": STACK_KERNEL, "achieved": alg3 / (ev3.mean() * 1e-3) / 1e9,
                                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg3 / (ev3.mean() * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -741,6 +780,8 @@ def main():
             res["stack_buffer_probe"] = probe
         if hbm_ring is not None:
             res["hbm_ring"] = hbm_ring
+        if verified is not None:
+            res["stack_verified"] = verified
         if shard_leg is not None:
             res["configs4_shard_on_one_gpu"] = shard_leg
         if c3_leg is not None:

@@ -89,16 +89,15 @@ int tq_set_min_qubit_errors(tq_env* h, int n_errors);
 int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_final, double p_delta);
 
 /* Set-up helper for the caller-owned stack buffer (np.concatenate's result, numba/util_actor.py:37-39, written every
- * step).  On MI355X the rate of every write stream into a freshly mapped buffer -- the stack write, a plain fill,
- * hipMemset -- is 5.3-6.5 TB/s depending on the box and the allocation (plain hipMalloc / torch.empty buffers are among
- * the slow ones in a PyTorch process).  tq_stack_alloc returns device memory of at least `bytes` bytes made of 2 MiB
- * physical chunks (HIP virtual memory API) that has been "walked in": mapped at 17 virtual addresses (128 MiB or 1/16 of
- * the buffer apart, whichever is more) inside a window reserved for it and written once (hipMemset, zeros) at each;
- * after that the last address -- the one returned -- writes at 7.0-7.2 TB/s on slow and fast boxes alike and stays
- * that fast (tools/placement_bench.hip, tools/walk_probe.py, profiles/r03_stack_write_ab.txt section 12: mapping
- * without writing, writing repeatedly at one address, or two addresses in turn do nothing).  Costs ~0.2 s per GB;
- * allocates, maps and synchronises.  Any other device allocation
- * works as `out` of tq_persp_write just as well. */
+ * step).  On MI355X a buffer has a write rate of its own for every write stream into it -- the stack write, a plain
+ * fill, hipMemset -- between 5.2 and 6.9 TB/s, different from allocation to allocation and from box to box; plain
+ * hipMalloc / torch.empty buffers were the slow kind in every PyTorch process of round 3 (5.1-5.5 TB/s), buffers made
+ * of 2 MiB physical chunks (HIP virtual memory API) the fast kind in most (profiles/r03_stack_write_ab.txt).
+ * tq_stack_alloc returns device memory of at least `bytes` bytes made of such chunks, each mapped once behind one
+ * virtual range, zero-filled, and CHECKED: every 2 MiB page is verified to be reached through its own address (this
+ * API leaves stale address translations behind when addresses are re-used; the library never re-uses one, never gives
+ * an address range back, and does not hand out a buffer that fails the check).  Allocates, maps and synchronises; any
+ * other device allocation works as `out` of tq_persp_write just as well. */
 int tq_stack_alloc(int device, uint64_t bytes, void** out);
 int tq_stack_free(void* ptr);
 

@@ -803,23 +803,23 @@ def test_chunked_stack_buffer_and_placement_probe(T):
     L = T.load()
     assert L.tq_stack_free(C.c_void_p(ref.data_ptr())) == -1 and b"tq_stack_alloc" in L.tq_last_error()   # not one of ours
     assert L.tq_stack_free(None) == 0
-    # the walk leaves nothing behind: allocate-and-free cycles return the memory, failures too
+    # allocate-and-free cycles return the memory, failures too
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free0, _ = torch.cuda.mem_get_info()
     for _ in range(4):
-        w = T.alloc_walked((300 << 20,), torch.uint8, gpu.device)      # 300 MiB: walked over 16 x 128 MiB of addresses
+        w = T.alloc_chunked((300 << 20,), torch.uint8, gpu.device)
         assert w.data_ptr() % (2 << 20) == 0 and bool((w == 0).all())             # zero-filled
         w[::4097] = 7
         assert int(w[::4097].sum().item()) == 7 * len(w[::4097])
         del w
-    tiny = T.alloc_walked((3, 5), torch.int32, gpu.device)
+    tiny = T.alloc_chunked((3, 5), torch.int32, gpu.device)
     tiny[:] = 5
     assert int(tiny.sum().item()) == 75
     del tiny
     p_ = C.c_void_p(None)
     assert L.tq_stack_alloc(0, 0, C.byref(p_)) == -1                    # bytes == 0
-    assert L.tq_stack_alloc(0, 1 << 46, C.byref(p_)) == -2 and not p_.value     # 64 TiB: fails, cleans up
+    assert L.tq_stack_alloc(0, 1 << 46, C.byref(p_)) in (-1, -2) and not p_.value     # 64 TiB: refused, nothing left behind
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
@@ -862,3 +862,57 @@ def test_hip_equals_the_host_twin_call_for_call(T, d, strategy):
     assert np.array_equal(gblk.buf.cpu().numpy()[:hblk.size], hblk)        # priorities: zeros on both sides
     gpu.close()
     tw.close()
+
+
+def test_reused_stack_buffer_of_the_policy_glue(T):
+    """EnvSet.generatePerspectiveReused: the stack in a buffer the EnvSet keeps (tq_stack_alloc memory), returned
+    as views -- same contents as generatePerspective at every step, same storage from step to step."""
+    d, n = 7, 1500
+    gpu, ora = make_pair(T, d, n, seed=8, numpy_io=False)
+    gpu.resetAll()
+    ptrs = set()
+    for t in range(5):
+        per, pos, cnt = gpu.generatePerspective()
+        rper, rpos, rcnt = gpu.generatePerspectiveReused()
+        assert torch.equal(per, rper) and torch.equal(pos, rpos) and torch.equal(cnt, rcnt)
+        ptrs.add(rper.data_ptr())
+        act, qv = gpu.selectAction(None, np.ones(n))               # the positions the glue remembers are the views
+        gpu.actorStep(act)
+    assert len(ptrs) == 1
+    h8, _, _ = gpu.generatePerspectiveReused(dtype=torch.uint8)
+    f32, _, _ = gpu.generatePerspective()
+    assert torch.equal(h8.float(), f32) and h8.data_ptr() not in ptrs
+    gpu.check()
+    gpu.close()
+
+
+def test_chunked_buffers_never_alias(T):
+    """tq_stack_alloc buffers of changing sizes, allocated, written with patterns of their own and freed in turn: no
+    buffer ever shows another buffer's bytes, and position-dependent patterns come back intact.  (The HIP virtual
+    memory API leaves stale address translations behind when an address is used again for another physical chunk -- after
+    hipMemAddressFree + a later reservation of the same range, or after hipMemUnmap + hipMemMap: a later buffer read and
+    wrote the previous tenant's pages.  The library never re-uses an address and checks every buffer before handing it
+    out, csrc/toricenv.hip.)"""
+    dev = torch.device("cuda:0")
+    sizes = [(600 * 18 * 72, 600 * 18 * 12), (600 * 50 * 200, 600 * 50 * 12), (600 * 98 * 392, 600 * 98 * 12),
+             (600 * 162 * 648, 600 * 162 * 12), (600 * 50 * 200, 600 * 50 * 12), (600 * 98 * 392, 600 * 98 * 12)]
+    for rep in range(2):
+        for na, nb in sizes:
+            a = T.alloc_chunked((na,), torch.uint8, dev)
+            b = T.alloc_chunked((nb,), torch.uint8, dev)
+            a.fill_(0x3F)
+            torch.cuda.synchronize()
+            assert not bool(b.any()), (rep, na, nb)
+            b.fill_(0x11)
+            torch.cuda.synchronize()
+            assert bool((a == 0x3F).all()), (rep, na, nb)
+            del a, b
+    for mib in (130, 200, 333, 2500):
+        n = (mib << 20) // 4
+        w = T.alloc_chunked((n,), torch.int32, dev)
+        pat = torch.arange(n, dtype=torch.int32, device=dev)
+        w.copy_(pat)                                               # straight after the allocation, no other call in between
+        torch.cuda.synchronize()
+        assert torch.equal(w, pat), mib
+        del w, pat
+    torch.cuda.empty_cache()

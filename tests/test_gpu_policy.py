@@ -451,5 +451,7 @@ def test_nn11_on_the_device_stack(T):
     T.seed_select(5)
     a2, q2 = T.selectActionBatch(3, 0.0, d // 2, d, ora.states.astype(np.int64), model_gpu, "cuda")
     o2, oq2, _ = O.select_action_batch(q_gpu.cpu().numpy(), boff, bpos, 0.0, 5, np.arange(n), 0, 0, domain=O.DOMAIN_SEL_CALL)
-    assert np.array_equal(a2, o2) and np.array_equal(q2, oq2.astype(np.float64))
+    # the entry point runs its own forward pass (fixed-shape chunks, zero-padded): another batch shape, possibly another
+    # MIOpen kernel and summation order than q_gpu above -- Q-values to 1e-5 absolute, the greedy choice exact
+    assert np.array_equal(a2, o2) and float(np.abs(q2 - oq2.astype(np.float64)).max()) < 1e-5
     gpu.close()

@@ -6,7 +6,7 @@ for gfx950 behind a C-ABI (include/toricenv.h), with the reference's Python surf
 Import it as ``toric_rl_decoder_amd`` (the directory name has a hyphen).
 """
 from ._lib import ToricEnvError, build, load, LIB_PATH  # noqa: F401
-from .envset import (EnvSet, ToricEnv, TransitionBlock, alloc_stack, alloc_walked, generatePerspectiveBatch,  # noqa: F401
+from .envset import (EnvSet, ToricEnv, TransitionBlock, alloc_stack, alloc_chunked, generatePerspectiveBatch,  # noqa: F401
                      generateTransitionParallel, make, to_structured, transition_dtype, SUPPORTED_SIZES)
 
 from .policy import (NN_11, evaluate, predictMaxOptimized, seed_select, segment_max, selectActionBatch,  # noqa: F401,E402
@@ -14,5 +14,5 @@ from .policy import (NN_11, evaluate, predictMaxOptimized, seed_select, segment_
 
 from .actor import computePrioritiesParallel, run_actor  # noqa: F401,E402
 
-__all__ = ["computePrioritiesParallel", "run_actor", "NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "selectActionEnvSet", "seed_select", "EnvSet", "ToricEnv", "TransitionBlock", "alloc_stack", "alloc_walked", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
+__all__ = ["computePrioritiesParallel", "run_actor", "NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "selectActionEnvSet", "seed_select", "EnvSet", "ToricEnv", "TransitionBlock", "alloc_stack", "alloc_chunked", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
            "transition_dtype", "ToricEnvError", "build", "load", "LIB_PATH", "SUPPORTED_SIZES"]

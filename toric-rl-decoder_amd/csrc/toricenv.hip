@@ -28,11 +28,15 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// A failed HIP call is reported through the return code; the runtime's sticky "last error" is cleared so that the
+// caller's next launch check (PyTorch's, say) does not trip over it.
 #define HIPCHECK(expr)                                                                         \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess)                                                                  \
+        if (_e != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
             return fail(TQ_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                      \
     } while (0)
 
 #define KCHECK() HIPCHECK(hipGetLastError())
@@ -243,60 +247,60 @@ int tq_version(void) { return TQ_VERSION; }
 
 // ---- stack buffers backed by 2 MiB physical chunks (HIP virtual memory API)
 namespace {
-// A tq_stack_alloc buffer: 2 MiB physical chunks behind a virtual address window of its own, "walked in".
-// Measured on MI355X (tools/placement_bench.hip, profiles/r03_stack_write_ab.txt section 12): the rate of every write
-// stream into a freshly mapped buffer -- the stack write, hipMemset -- is 5.3-6.5 TB/s depending on the box; after the
-// same physical chunks have been mapped at a series of SHIFTED virtual addresses and written once at each of them, the
-// last address writes at 7.0-7.2 TB/s, and stays that fast.  Mapping without writing, writing repeatedly at one
-// address, or going back and forth between two addresses does nothing; the walk has to cover about the buffer's own
-// size (a 6.4 GiB buffer: 16 x 128 MiB is not enough, 16 x 256 MiB and 8 x 512 MiB are) in 8 or more steps.
-constexpr int STACK_WALK_STEPS = 16;
-constexpr size_t STACK_WALK_MIN_SHIFT = (size_t)128 << 20;
+// A tq_stack_alloc buffer: 2 MiB physical chunks (HIP virtual memory API), each mapped once behind one virtual range.
+//
+// Two hazards of this API on this stack (ROCm 7.2, MI355X), both met in round 3 and both guarded against here:
+//  * hipMemUnmap + hipMemMap of a different chunk at the same address leaves STALE TRANSLATIONS behind: kernels went on
+//    reading and writing the previous chunk through that address (78 % of a 600 MiB buffer, indefinitely: a
+//    hipDeviceSynchronize, a second of sleep, a 1 MiB hipMalloc + hipFree changed nothing; a 64 MiB hipMalloc + hipFree
+//    or a stream creation did).  Writes through such aliased translations LOOK fast -- 7.0 TB/s for a stack that is
+//    wrong in 70 % of its elements -- which cost this round an afternoon (profiles/r03_stack_write_ab.txt section 12).
+//    Nothing is ever re-mapped here.
+//  * the same happens across buffers when hipMemAddressFree gives an address range back and a later reservation
+//    receives it again: the new buffer reads and writes the previous tenant's pages.  Address ranges are therefore
+//    never given back (2 MiB-rounded buffer sizes out of a 128 TiB address space).
+// And every buffer is CHECKED before it is handed out: the driver is made to invalidate the device's translations
+// (a 64 MiB hipMalloc + hipFree), every 2 MiB page gets a tag of its own through its address, and every workgroup of a
+// grid that covers all CUs reads every page's tag back.
 struct ChunkedAlloc {
-    char* window = nullptr;
-    size_t window_bytes = 0, bytes = 0, chunk = 0, offset = 0;
+    char* va = nullptr;
+    size_t bytes = 0, chunk = 0, mapped = 0;
     int device = 0;
-    std::vector<hipMemGenericAllocationHandle_t> h;
-    char* va() const { return window + offset; }
 };
 std::mutex g_alloc_mu;
-std::vector<ChunkedAlloc*> g_allocs;
+std::vector<ChunkedAlloc> g_allocs;
 
-// maps every chunk of `a` at window + offset; on failure nothing stays mapped there
-hipError_t chunked_map(ChunkedAlloc* a, size_t offset) {
-    char* va = a->window + offset;
-    size_t mapped = 0;
-    hipError_t e = hipSuccess;
-    for (size_t i = 0; i < a->h.size() && e == hipSuccess; ++i) {
-        e = hipMemMap(va + i * a->chunk, a->chunk, 0, a->h[i], 0);
-        if (e == hipSuccess) ++mapped;
-    }
-    if (e == hipSuccess) {
-        hipMemAccessDesc acc = {};
-        acc.location.type = hipMemLocationTypeDevice;
-        acc.location.id = a->device;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        e = hipMemSetAccess(va, a->bytes, &acc, 1);
-    }
-    if (e != hipSuccess)
-        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap(va + i * a->chunk, a->chunk);
-    if (e == hipSuccess) a->offset = offset;
-    return e;
+__global__ void k_page_tag(char* base, size_t chunk, size_t n, int write) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) *reinterpret_cast<unsigned long long*>(base + i * chunk) = write ? (0x7a6b5c4d3e2f1001ull ^ (unsigned long long)i) : 0ull;
 }
-// every chunk was mapped by a hipMemMap of its own and is unmapped the same way
-hipError_t chunked_unmap(ChunkedAlloc* a, size_t count) {
-    hipError_t e = hipSuccess;
-    for (size_t i = 0; i < count; ++i) {
-        const hipError_t x = hipMemUnmap(a->va() + i * a->chunk, a->chunk);
-        if (x != hipSuccess) e = x;
-    }
-    return e;
+__global__ void k_page_check(const char* base, size_t chunk, size_t n, int* bad) {
+    int mine = 0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x)
+        mine += *reinterpret_cast<const volatile unsigned long long*>(base + i * chunk) != (0x7a6b5c4d3e2f1001ull ^ (unsigned long long)i);
+    if (mine) atomicAdd(bad, mine);
 }
-void chunked_release(ChunkedAlloc* a, bool is_mapped) {
-    if (is_mapped) (void)chunked_unmap(a, a->h.size());
-    for (auto& x : a->h) (void)hipMemRelease(x);
-    if (a->window) (void)hipMemAddressFree(a->window, a->window_bytes);
-    delete a;
+// 0 = every page of the buffer is reached through its own address from everywhere; > 0 = pages that are not; < 0 = HIP error
+long long translation_check(char* va, size_t chunk, size_t n) {
+    void* flush = nullptr;                                    // a mapping of its own, made and torn down: the tear-down
+    if (hipMalloc(&flush, (size_t)64 << 20) != hipSuccess) return -1;      // invalidates the process's translations
+    if (hipFree(flush) != hipSuccess) return -1;
+    int* scratch = nullptr;
+    if (hipMalloc((void**)&scratch, sizeof(int)) != hipSuccess) return -1;
+    long long result = -1;
+    if (hipMemsetAsync(scratch, 0, sizeof(int), nullptr) == hipSuccess) {
+        hipLaunchKernelGGL(k_page_tag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, va, chunk, n, 1);
+        hipLaunchKernelGGL(k_page_check, dim3(2048), dim3(64), 0, nullptr, (const char*)va, chunk, n, scratch);
+        hipLaunchKernelGGL(k_page_check, dim3(2048), dim3(64), 0, nullptr, (const char*)va, chunk, n, scratch);
+        hipLaunchKernelGGL(k_page_tag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, va, chunk, n, 0);
+        int bad = 0;
+        if (hipMemcpy(&bad, scratch, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && hipGetLastError() == hipSuccess) result = bad;
+    }
+    (void)hipFree(scratch);
+    return result;
+}
+void chunked_unmap(char* va, size_t chunk, size_t count) {    // every chunk was mapped by a call of its own and is unmapped the same way
+    for (size_t i = 0; i < count; ++i) (void)hipMemUnmap(va + i * chunk, chunk);
 }
 }  // namespace
 
@@ -306,75 +310,68 @@ int tq_stack_alloc(int device, uint64_t bytes, void** out) {
     if (bytes == 0) return fail(TQ_E_INVALID, "bytes must be > 0");
     DeviceGuard guard;
     if (int rc = guard.enter_device(device)) return rc;
-    // TORIC_STACK_WALK="steps,shift MiB" overrides the walk (experiments; "0,0" = map once)
-    int steps = STACK_WALK_STEPS;
-    size_t shift = ((size_t)bytes + STACK_WALK_STEPS - 1) / STACK_WALK_STEPS;     // the walk covers the buffer's own size
-    if (shift < STACK_WALK_MIN_SHIFT) shift = STACK_WALK_MIN_SHIFT;
-    if (const char* w = getenv("TORIC_STACK_WALK")) {
-        int s_ = 0, m_ = 0;
-        if (sscanf(w, "%d,%d", &s_, &m_) == 2 && s_ >= 0 && s_ <= 256 && m_ >= 0 && m_ <= 65536) { steps = s_; shift = (size_t)m_ << 20; }
-    }
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = device;
     size_t gran = 0;
     HIPCHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-    ChunkedAlloc* a = new (std::nothrow) ChunkedAlloc();
-    if (!a) return fail(TQ_E_HIP, "out of host memory");
-    a->chunk = (((size_t)2 << 20) + gran - 1) / gran * gran;
-    shift = (shift + a->chunk - 1) / a->chunk * a->chunk;
-    const size_t n = ((size_t)bytes + a->chunk - 1) / a->chunk;
-    a->bytes = n * a->chunk;
-    a->device = device;
-    a->window_bytes = a->bytes + (size_t)steps * shift;
-    hipError_t e = hipMemAddressReserve((void**)&a->window, a->window_bytes, 0, nullptr, 0);
-    if (e != hipSuccess) {
-        const size_t wanted = a->window_bytes;
-        a->window = nullptr;
-        chunked_release(a, false);
-        return fail(TQ_E_HIP, "reserving %zu bytes of virtual addresses failed: %s", wanted, hipGetErrorString(e));
-    }
-    a->h.reserve(n);
+    size_t chunk = (size_t)2 << 20;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = ((size_t)bytes + chunk - 1) / chunk;
+    if (n > ((size_t)1 << 40) / chunk) return fail(TQ_E_INVALID, "%llu bytes is more than a device holds", (unsigned long long)bytes);
+    void* va = nullptr;
+    HIPCHECK(hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0));
+    size_t mapped = 0;
+    hipError_t e = hipSuccess;
     for (size_t i = 0; i < n && e == hipSuccess; ++i) {
         hipMemGenericAllocationHandle_t hnd;
-        e = hipMemCreate(&hnd, a->chunk, &prop, 0);
-        if (e == hipSuccess) a->h.push_back(hnd);
-    }
-    // the walk: map, write once, unmap, one shift further; the buffer stays at the last address
-    for (int k = 0; k <= steps && e == hipSuccess; ++k) {
-        e = chunked_map(a, (size_t)k * shift);
+        e = hipMemCreate(&hnd, chunk, &prop, 0);
         if (e != hipSuccess) break;
-        if (steps > 0) {
-            e = hipMemsetAsync(a->va(), 0, a->bytes, nullptr);
-            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-        }
-        if (e == hipSuccess && k < steps) e = chunked_unmap(a, a->h.size());
-        else if (e != hipSuccess) (void)chunked_unmap(a, a->h.size());
+        e = hipMemMap((char*)va + i * chunk, chunk, 0, hnd, 0);
+        (void)hipMemRelease(hnd);                            // the mapping keeps the memory alive
+        if (e == hipSuccess) ++mapped;
     }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, n * chunk, &acc, 1);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(va, 0, n * chunk, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
-        chunked_release(a, false);
+        chunked_unmap((char*)va, chunk, mapped);             // the address range stays reserved (see above)
+        (void)hipGetLastError();
         return fail(TQ_E_HIP, "chunked allocation of %llu bytes failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
     }
+    const long long bad = translation_check((char*)va, chunk, n);
+    if (bad != 0) {
+        chunked_unmap((char*)va, chunk, mapped);
+        (void)hipGetLastError();
+        return fail(TQ_E_HIP, "%lld pages of the new buffer are not reached through their own addresses (stale address translations): "
+                              "not handing it out", bad);
+    }
     std::lock_guard<std::mutex> lock(g_alloc_mu);
-    g_allocs.push_back(a);
-    *out = a->va();
+    g_allocs.push_back(ChunkedAlloc{(char*)va, n * chunk, chunk, mapped, device});
+    *out = va;
     return TQ_OK;
 }
 
 int tq_stack_free(void* ptr) {
     if (!ptr) return TQ_OK;
-    ChunkedAlloc* a = nullptr;
+    ChunkedAlloc a;
     {
         std::lock_guard<std::mutex> lock(g_alloc_mu);
         for (size_t i = 0; i < g_allocs.size(); ++i)
-            if (g_allocs[i]->va() == ptr) { a = g_allocs[i]; g_allocs[i] = g_allocs.back(); g_allocs.pop_back(); break; }
+            if (g_allocs[i].va == ptr) { a = g_allocs[i]; g_allocs[i] = g_allocs.back(); g_allocs.pop_back(); break; }
     }
-    if (!a) return fail(TQ_E_INVALID, "pointer did not come from tq_stack_alloc");
+    if (!a.va) return fail(TQ_E_INVALID, "pointer did not come from tq_stack_alloc");
     DeviceGuard guard;
-    if (int rc = guard.enter_device(a->device)) { std::lock_guard<std::mutex> lock(g_alloc_mu); g_allocs.push_back(a); return rc; }
+    if (int rc = guard.enter_device(a.device)) { std::lock_guard<std::mutex> lock(g_alloc_mu); g_allocs.push_back(a); return rc; }
     (void)hipDeviceSynchronize();
-    chunked_release(a, true);
+    chunked_unmap(a.va, a.chunk, a.mapped);                  // the physical chunks go back; the address range is not given back
+    (void)hipGetLastError();
     return TQ_OK;
 }
 const char* tq_last_error(void) { return g_err; }

@@ -142,12 +142,12 @@ class _ChunkedBuffer:
             pass
 
 
-def alloc_walked(shape, dtype=torch.float32, device=None):
-    """A device tensor of ``shape`` / ``dtype`` in tq_stack_alloc memory: 2 MiB physical chunks that the call has
-    "walked in" (mapped and written once at 17 shifted virtual addresses) -- on MI355X every write stream into such a
-    buffer runs at 7.0-7.2 TB/s against 5.2-5.5 into a torch.empty buffer (include/toricenv.h; ~0.2 s per GB of
-    set-up, at least 128 MiB of walk).  For buffers that are written in full every step: the stack, the positions.
-    Zero-filled.  The memory is released when the returned tensor (and every view of it) is gone."""
+def alloc_chunked(shape, dtype=torch.float32, device=None):
+    """A device tensor of ``shape`` / ``dtype`` in tq_stack_alloc memory: 2 MiB physical chunks behind one virtual
+    range, zero-filled, every page verified to be reached through its own address (include/toricenv.h).  The kind of
+    allocation the stack write ran fastest on in most processes of round 3 (6.5-6.8 TB/s against 5.1-5.5 into
+    torch.empty buffers; on some boxes no kind is faster than another).  The memory is released when the returned
+    tensor (and every view of it) is gone."""
     dev = _require_gpu(device)
     shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
     nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
@@ -158,8 +158,8 @@ def alloc_walked(shape, dtype=torch.float32, device=None):
 
 
 def alloc_stack(capacity, size, dtype=torch.float32, device=None):
-    """A stack buffer (capacity, 2, d, d) of ``dtype`` from alloc_walked (tq_stack_alloc)."""
-    return alloc_walked((int(capacity), 2, int(size), int(size)), dtype, device)
+    """A stack buffer (capacity, 2, d, d) of ``dtype`` from alloc_chunked (tq_stack_alloc)."""
+    return alloc_chunked((int(capacity), 2, int(size), int(size)), dtype, device)
 
 
 class TransitionBlock:
@@ -276,6 +276,7 @@ class EnvSet:
     # ------------------------------------------------------------------ plumbing
     def close(self):
         self._parked = []
+        self.__dict__.pop("_stack_cache", None)
         if getattr(self, "_h", None) is not None and self._h.value:
             self._L.tq_destroy(self._h)
             self._h = C.c_void_p(None)
@@ -483,6 +484,31 @@ class EnvSet:
         """Free the candidates pickStackBuffer(park=True) kept."""
         self._parked = []
         torch.cuda.empty_cache()
+
+    def generatePerspectiveReused(self, dtype=torch.float32):
+        """generatePerspective for the current states into a stack buffer this EnvSet keeps and re-uses (allocated on
+        first use with alloc_chunked for the worst case, no_envs * 2*d*d perspectives -- 2.5 GB at 65 536 lattices of
+        d=7 in f32 -- without an allocation per step, in the kind of buffer the stack write runs fastest on).  -> (perspectives (P,2,d,d), positions (P,3), counts (N,)) as VIEWS of that buffer: valid until the
+        next call with the same dtype.  For loops that consume the stack at once (the policy's forward pass:
+        numba/util_actor.py:39-46); generatePerspective returns a result of its own like the reference does."""
+        cache = self.__dict__.setdefault("_stack_cache", {})
+        if dtype not in cache:
+            d = self.size
+            cap = self.no_envs * 2 * d * d
+            try:
+                buf = alloc_stack(cap, d, dtype, self.device)
+                pos = alloc_chunked((cap, 3), torch.int32, self.device)
+            except _lib.ToricEnvError:                            # no virtual-memory API on this driver
+                buf = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
+                pos = torch.empty((cap, 3), dtype=torch.int32, device=self.device)
+            cache[dtype] = (buf, pos)
+        buf, pos = cache[dtype]
+        counts, offsets = self.perspectiveCounts()
+        P = int(offsets[-1].item())
+        if P:
+            self.writePerspectives(buf, pos, offsets)
+        self._positions = pos[:P]
+        return buf[:P], pos[:P], counts
 
     def generatePerspective(self, states=None, dtype=torch.float32):
         """generatePerspectiveBatch + concatenate (numba/util_actor.py:33-39,56-67) for the current

@@ -71,7 +71,7 @@ def selectActionEnvSet(envs, model, epsilon, dtype=torch.float32, chunk=1 << 16)
     io = envs.numpy_io
     envs.numpy_io = False
     try:
-        persp, pos, _ = envs.generatePerspective(dtype=dtype)
+        persp, pos, _ = envs.generatePerspectiveReused(dtype=dtype)       # consumed at once by the forward pass
         q = _forward_chunked(model, persp, chunk)
         act, qv = envs.selectAction(q, epsilon, positions=pos)
     finally:

@@ -107,6 +107,8 @@ def test_bench_json_contract():
     assert set(nn["variants"]) == {"f32", "bf16"} and nn["variants"]["bf16"]["stack_dtype"] == "bf16"
     pr = j["stack_buffer_probe"]                              # set-up probe of the stack buffer's placement, reported in full
     assert pr["kinds"][0] == "torch.empty" and len(pr["write_ms"]) == pr["candidates"] >= 2 and 0 <= pr["chosen"] < pr["candidates"]
+    assert j["stack_verified"]["ok"] is True and j["stack_verified"]["wrong_bytes"] == 0      # the timed buffer holds the right bytes
+    assert "host_twin" in c and (c["host_twin"].get("value", 0) > 0 or "error" in c["host_twin"])
     assert r["kernel"] == "k_persp_stream" and "custom" in j["config"]["workload"]      # 8192 lattices: not a BASELINE config
     assert j["config"]["steady_state"] is True and 40 < j["perspectives_per_lattice"] < 98
     assert j["value"] > 1e6 and abs(j["value"] - 8192 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6

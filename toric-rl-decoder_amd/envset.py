@@ -443,7 +443,7 @@ class EnvSet:
         _, off = self.perspectiveCounts()
         off = off.clone()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ms, keep = [], []          # every candidate stays allocated until the choice is made: distinct placements
+        ms, keep, addrs = [], [], []   # every candidate stays allocated until the choice is made: distinct placements
         used = []
         for k in range(max(1, int(candidates))):
             kind = kinds[0] if k == 0 or len(kinds) == 1 else kinds[1 + (k - 1) % (len(kinds) - 1)]
@@ -457,6 +457,7 @@ class EnvSet:
                 c = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
             used.append("torch.empty" if kind == "torch" else "alloc_stack (2 MiB chunks)")
             keep.append(c)
+            addrs.append(hex(c.data_ptr()))
             t = []
             for r in range(int(launches) + 1):
                 e0.record()
@@ -474,7 +475,7 @@ class EnvSet:
         del keep, c
         if not park:
             torch.cuda.empty_cache()
-        report = {"candidates": len(ms), "write_ms": ms, "chosen": int(np.argmin(ms)), "kinds": used}
+        report = {"candidates": len(ms), "write_ms": ms, "chosen": int(np.argmin(ms)), "kinds": used, "addresses": addrs}
         if len(ms) > 2 and min(ms) > 0.9 * ms[0]:
             report["uniform"] = ("no candidate writes more than 10 % faster than candidate 0: on some boxes every buffer -- and "
                                  "every write stream, hipMemset included -- runs at one rate (profiles/r03_stack_write_ab.txt)")

@@ -349,6 +349,7 @@ int tq_stack_alloc(int device, uint64_t bytes, void** out) {
     if (bad != 0) {
         chunked_unmap((char*)va, chunk, mapped);
         (void)hipGetLastError();
+        if (bad < 0) return fail(TQ_E_HIP, "the check of the new buffer's address translations could not run (a HIP call failed)");
         return fail(TQ_E_HIP, "%lld pages of the new buffer are not reached through their own addresses (stale address translations): "
                               "not handing it out", bad);
     }

@@ -95,3 +95,4 @@ def test_product_never_imports_the_oracle():
     for path in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True) + glob.glob(os.path.join(pkg, "csrc", "*")):
         text = open(path, errors="ignore").read()
         assert "import oracle" not in text and "from oracle" not in text and "toric_oracle" not in text, path
+        assert "host_twin" not in text, path                 # the host twin of the ABI is test infrastructure too

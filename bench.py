@@ -218,6 +218,14 @@ def cpu_baseline(d, p, seed, budget_s):
                                       f"(oracle/host_twin.cpp, bit-plane algebra of csrc/lattice.hpp, OpenMP, {threads} threads), {dtt:.1f} s",
                             "one_core": {"value": v1t, "cores": 1, "perspectives_per_sec": pp1t,
                                          "sample": f"512 lattices x {s1t} steps, 1 thread, {dt1t:.1f} s"}}
+        out["c_oracle"] = {"value": out["value"], "cores": out["cores"], "sample": out["sample"],
+                           "perspectives_per_sec": out["perspectives_per_sec"], "one_core": dict(out["one_core"])}
+        if vt > out["value"]:                                     # the headline CPU number is the faster of the two ports
+            out.update({"value": vt, "sample": out["host_twin"]["sample"], "perspectives_per_sec": ppt, "which": "host_twin"})
+        else:
+            out["which"] = "c_oracle"
+        if v1t > out["one_core"]["value"]:
+            out["one_core"] = dict(out["host_twin"]["one_core"], which="host_twin")
     except Exception as e:                                        # the twin is an extra; the baseline above stands without it
         out["host_twin"] = {"error": repr(e)}
     L.tor_set_threads(threads)

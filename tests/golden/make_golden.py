@@ -12,11 +12,15 @@ What is imported from the reference (numpy half of the path, importable here):
                        computePrioritiesParallel
   src/util_learner.py  predictMaxOptimized (driven with an integer-weight linear model, so
                        its fp32 Q-values are exact and the expected maxima are bit-exact)
-The only shim is restoring the numpy-1 aliases np.int/np.bool/np.float that
-numpy 2 removed (src/util.py:10 uses np.int).  ``src/numba/*`` needs numba, which
-is absent here and stays absent: those files restate src/util.py (the reference's
-own tests/time_test_genPersp.py checks exactly that equivalence) and are read as
-text only.
+  src/numba/util.py        generatePerspectiveOptimized, rotate_state, shift_state
+  src/numba/util_actor.py  generatePerspectiveBatch (+ the np.concatenate / float32 cast of :33-39),
+                           _selectActionBatch_prime (greedy branch, forced ties)
+                       -- the variant PRODUCTION imports (src/Actor_mp.py:13).
+Shims: the numpy-1 aliases np.int/np.bool/np.float that numpy 2 removed (src/util.py:10 uses
+np.int), and -- numba is absent here and stays absent -- an identity stand-in for the two names
+``src/numba/*`` takes from it: ``njit = jit = identity decorator`` and ``numba.typed.List = list``
+(SURVEY.md 8(c) records this import).  The decorated functions are plain Python/numpy, so the
+stand-in runs exactly the reference's source text, un-jitted; outputs go to ``numba_d*.npz``.
 
 The gym_ToricCode env (reset/step/syndrome) is not in the reference tree, so no
 vector for it can be generated from the reference: env_kat_d*.npz below holds
@@ -45,10 +49,34 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
 
+
+def _install_numba_stand_in():
+    """`from numba import njit, jit` / `from numba.typed import List` with numba absent: decorators that return
+    the function unchanged (bare and called forms) and the builtin list."""
+    import types
+
+    def identity(*args, **kwargs):
+        if len(args) == 1 and callable(args[0]) and not kwargs:
+            return args[0]
+        return lambda f: f
+    nb = types.ModuleType("numba")
+    nb.njit = nb.jit = identity
+    typed = types.ModuleType("numba.typed")
+    typed.List = list
+    nb.typed = typed
+    assert "numba" not in sys.modules
+    sys.modules["numba"] = nb
+    sys.modules["numba.typed"] = typed
+
+
+_install_numba_stand_in()
+
 import torch                     # noqa: E402
 import src.util as RU            # noqa: E402  (reference)
 import src.util_actor as RA      # noqa: E402  (reference)
 import src.util_learner as RL    # noqa: E402  (reference)
+import src.numba.util as NU      # noqa: E402  (reference, the variant production imports)
+import src.numba.util_actor as NA  # noqa: E402  (reference)
 from oracle import toric_oracle as O  # noqa: E402
 
 
@@ -130,6 +158,69 @@ def learner_and_priority_vectors(d, rng):
                 pr_Q=Q.astype(np.float32), pr_discount=np.float64(0.95), pr_out=pr)
 
 
+def numba_variant_vectors(d, states, rp, rpos, rcnt, rng):
+    """The numba-source variant (src/numba/util.py:28-76, src/numba/util_actor.py:33-39,56-107) on the same states:
+    asserted equal to the numpy variant and to both oracle forms, outputs frozen.  The batch + concatenate of
+    :33-38 cannot take a state without defects (np.concatenate of a (0,) with (n,3) position lists raises), so it
+    runs on the non-empty states, in order; `nonempty` is frozen with it."""
+    gs = int(d / 2)
+    n = states.shape[0]
+    offs = np.zeros(n + 1, np.int64)
+    np.cumsum(rcnt, out=offs[1:])
+    # --- generatePerspectiveOptimized, state by state (empty states included: two empty lists)
+    for i, s in enumerate(states):
+        per, pos = NU.generatePerspectiveOptimized(gs, d, s.astype(np.int64))
+        assert len(per) == len(pos) == rcnt[i]
+        if len(per):
+            assert np.array_equal(np.asarray(per), rp[offs[i]:offs[i + 1]])
+            assert np.array_equal(np.asarray(pos, np.int64), rpos[offs[i]:offs[i + 1]])
+    # --- rotate_state / shift_state of the variant
+    ar = np.arange(2 * d * d).reshape(2, d, d)
+    assert np.array_equal(NU.rotate_state(ar), RU.rotate_state(ar))
+    na, nb_ = NU.shift_state(1, d - 1, ar, ar[::-1].copy(), gs)
+    ra, rb = RU.shift_state(1, d - 1, ar, ar[::-1].copy(), gs)
+    assert np.array_equal(na, ra) and np.array_equal(nb_, rb)
+    # --- generatePerspectiveBatch + the flatten of selectActionBatch (:33-39)
+    nz = rcnt > 0
+    sub = states[nz].astype(np.int64)
+    perspectives, positions, splice_idx = NA.generatePerspectiveBatch(gs, d, sub)
+    splice_idx = np.cumsum(splice_idx)
+    positions = np.concatenate(positions)
+    perspectives = np.concatenate(perspectives)
+    as_tensor = torch.from_numpy(perspectives).type('torch.Tensor')            # :39, what the network is fed
+    assert as_tensor.dtype == torch.float32 and np.array_equal(as_tensor.numpy(), perspectives.astype(np.float32))
+    assert np.array_equal(perspectives, rp) and np.array_equal(positions, rpos)    # empty states contribute nothing
+    assert np.array_equal(splice_idx, offs[1:][nz])
+    bp, bpos, bcnt, boff = O.generate_perspective_batch(states[nz])
+    assert np.array_equal(bp, perspectives) and np.array_equal(bpos, positions) and np.array_equal(boff[1:], splice_idx)
+    op_, opos, ocnt = O.generate_perspective_batch_ref(gs, d, sub)
+    assert np.array_equal(op_, perspectives) and np.array_equal(opos, positions)
+    # --- _selectActionBatch_prime, greedy everywhere, ties forced: inside a slice, across ops of one row, and
+    # a slice whose every entry is equal (first (p, a) in row-major order must win, :93-95)
+    q = rng.standard_normal((perspectives.shape[0], 3)).astype(np.float32)
+    first = np.concatenate(([0], splice_idx[:-1]))
+    for k, (lo, hi) in enumerate(zip(first, splice_idx)):
+        if k % 3 == 0 and hi - lo >= 2:
+            m = q[lo:hi].max() + 1.0
+            rows = rng.choice(hi - lo, size=2, replace=False)
+            q[lo + rows[0], rng.integers(3)] = m
+            q[lo + rows[1], rng.integers(3)] = m
+        if k % 7 == 1:
+            q[lo + rng.integers(hi - lo), :] = q[lo:hi].max() + 2.0
+        if k % 11 == 2:
+            q[lo:hi] = 0.25
+    acts, qv = NA._selectActionBatch_prime(q, splice_idx, positions, np.ones(len(splice_idx), bool))
+    assert acts.dtype == np.float64 and qv.dtype == np.float64
+    oact, oqv, _ = O.select_action_batch(q, np.concatenate(([0], splice_idx)), positions, 0.0, 1, np.arange(len(splice_idx)), 1, 0)
+    assert np.array_equal(acts.astype(np.int64), oact) and np.array_equal(qv.astype(np.float32), oqv)
+    # the numpy variant's selection (util_actor.py:189-221) on the same table agrees as well
+    ract, rqv = RA.selectActionParallel_prime([q[a:b] for a, b in zip(first, splice_idx)],
+                                              [positions[a:b] for a, b in zip(first, splice_idx)], np.ones(len(splice_idx), bool))
+    assert np.array_equal(ract, acts.astype(np.int64)) and np.array_equal(rqv.astype(np.float64), qv)
+    return dict(nonempty=nz, perspectives=perspectives.astype(np.uint8), positions=positions.astype(np.uint8),
+                splice_idx=splice_idx.astype(np.int64), sel_q=q, sel_actions=acts.astype(np.uint8), sel_qv=qv.astype(np.float32))
+
+
 def main():
     rng = np.random.default_rng(20200318)
     report = []
@@ -189,6 +280,9 @@ def main():
         oact, oqv, _ = O.select_action_batch(q, offs, rpos, 0.0, 1, np.arange(n), 1, 0)
         assert np.array_equal(ract, oact[nz]) and np.array_equal(rqv.astype(np.float32), oqv[nz])
 
+        np.savez_compressed(os.path.join(HERE, f"numba_d{d}.npz"),
+                            **numba_variant_vectors(d, states, rp, rpos, rcnt, np.random.default_rng(9000 + d)))
+
         np.savez_compressed(os.path.join(HERE, f"learner_d{d}.npz"),
                             **learner_and_priority_vectors(d, np.random.default_rng(7000 + d)))
 
@@ -219,7 +313,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "plot_syndroms_d5.npz"), qubits=s)
 
     for d, n, P in report:
-        print(f"d={d}: {n} states, {P} perspectives frozen; reference == oracle_ref == oracle_batch")
+        print(f"d={d}: {n} states, {P} perspectives frozen; reference (numpy variant) == reference (numba-source variant) "
+              f"== oracle_ref == oracle_batch")
 
 
 if __name__ == "__main__":

@@ -125,6 +125,24 @@ def test_golden_reference_vectors(T, golden_dir, d):
     assert np.array_equal(rec["next_perspective"], g["t_next_perspective"])
     assert np.array_equal(rec["action"]["position"], g["t_position"]) and np.array_equal(rec["action"]["op"], g["t_op"])
     assert np.array_equal(rec["reward"], g["t_reward"]) and np.array_equal(rec["terminal"], g["t_terminal"])
+    # the numba-source variant production imports (src/numba/util_actor.py:33-39,56-107), frozen from the reference's
+    # own source: batch + concatenate + float32 cast, then the greedy selection with forced ties
+    nb = np.load(os.path.join(golden_dir, f"numba_d{d}.npz"), allow_pickle=False)
+    st = g["states"][nb["nonempty"]]
+    per, pos, cnt, off = T.generatePerspectiveBatch(d // 2, d, st, dtype=torch.float32, return_offsets=True)
+    assert per.dtype == torch.float32 and np.array_equal(per.cpu().numpy(), nb["perspectives"].astype(np.float32))
+    assert np.array_equal(pos.cpu().numpy(), nb["positions"])
+    assert np.array_equal(off.cpu().numpy()[1:], nb["splice_idx"])
+    acts, qv = T._selectActionBatch_prime(nb["sel_q"], nb["splice_idx"], nb["positions"], np.ones(st.shape[0], bool))
+    assert acts.dtype == np.float64 and qv.dtype == np.float64
+    assert np.array_equal(acts, nb["sel_actions"].astype(np.float64)) and np.array_equal(qv, nb["sel_qv"].astype(np.float64))
+    # the same through the handle-bound kernel (EnvSet.selectAction), eps = 0
+    env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+    hs = T.EnvSet(env, st.shape[0], seed=1, numpy_io=True)
+    hs.resetAll()
+    a2, q2 = hs.selectAction(nb["sel_q"], 0.0, positions=pos, offsets=off)
+    assert np.array_equal(a2, nb["sel_actions"]) and np.array_equal(q2, nb["sel_qv"])
+    hs.close()
 
 
 @pytest.mark.parametrize("dtype", (torch.float16, torch.bfloat16, torch.uint8))

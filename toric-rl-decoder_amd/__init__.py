@@ -10,7 +10,7 @@ from .envset import (EnvSet, ToricEnv, TransitionBlock, alloc_stack, alloc_chunk
                      generateTransitionParallel, make, to_structured, transition_dtype, SUPPORTED_SIZES)
 
 from .policy import (NN_11, evaluate, predictMaxOptimized, seed_select, segment_max, selectActionBatch,  # noqa: F401,E402
-                     selectActionEnvSet)
+                     selectActionEnvSet, _selectActionBatch_prime)
 
 from .actor import computePrioritiesParallel, run_actor  # noqa: F401,E402
 

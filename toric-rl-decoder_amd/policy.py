@@ -121,6 +121,41 @@ def selectActionBatch(number_of_actions, epsilon, grid_shift, toric_size, state,
     return actions.cpu().numpy().astype(np.int64), qv.cpu().numpy().astype(np.float64)
 
 
+def _selectActionBatch_prime(q_values_table, splice_idx, positions, greedy, device=None):
+    """Drop-in for src/numba/util_actor.py:69-107 on the device -- same arguments: the (P,3) Q-table of all
+    perspectives, ``splice_idx`` = cumsum of the perspectives per state (:31), ``positions`` (P,3), ``greedy`` bool
+    (N,) -> (actions (N,4) float64, q_values (N,3) float64) like the reference's np.empty defaults.  greedy[i]: the
+    first (perspective, op) attaining the maximum of the state's slice in row-major order (:93-95); otherwise a
+    uniform perspective and op (:97-98) from the Philox stream of seed_select() (upstream: numpy's unseeded global
+    RNG).  A state with an empty slice (the reference raises on it) gets action op 0 and zero q_values."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError("device must be a cuda (ROCm) device: the toric env has no CPU path")
+    q = torch.as_tensor(np.ascontiguousarray(q_values_table) if not torch.is_tensor(q_values_table) else q_values_table)
+    q = q.to(device=dev, dtype=torch.float32).contiguous()
+    sp = torch.as_tensor(np.asarray(splice_idx, np.int64) if not torch.is_tensor(splice_idx) else splice_idx).to(dev, torch.int64)
+    n = int(sp.numel())
+    offsets = torch.zeros(n + 2, dtype=torch.int64, device=dev)[:n + 1]       # even length behind it: 16-byte aligned rows
+    offsets[1:] = sp
+    pos = torch.as_tensor(np.ascontiguousarray(positions) if not torch.is_tensor(positions) else positions)
+    pos = pos.to(device=dev, dtype=torch.int32).contiguous()
+    if q.shape[0] != pos.shape[0] or (n and int(sp[-1].item()) != q.shape[0]):
+        raise ValueError("q_values_table / positions / splice_idx do not describe the same perspectives")
+    g = torch.as_tensor(np.asarray(greedy, bool) if not torch.is_tensor(greedy) else greedy).to(dev)
+    if g.numel() != n:
+        raise ValueError("greedy must have one entry per state")
+    eps = (~g.bool()).to(torch.float64).contiguous()          # greedy iff (1 - eps) > U with U in [0,1): eps 0 -> always, 1 -> never
+    actions = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    qv = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    call = _select_rng["calls"]
+    _select_rng["calls"] = call + 1
+    if n:
+        with torch.cuda.device(dev):
+            check(_lib.load().tq_states_select_action(n, _ptr(q), _ptr(offsets), _ptr(pos), _ptr(eps),
+                                                      _select_rng["seed"], call, 0, _ptr(actions), _ptr(qv), _stream()))
+    return actions.cpu().numpy().astype(np.float64), qv.cpu().numpy().astype(np.float64)
+
+
 def segment_max(q_table, offsets, largest=None):
     """out[i] = max of q_table[offsets[i]:offsets[i+1]] (0 for an empty slice); with ``largest``
     (device int32[1]) the reference's zero padding is reproduced."""

@@ -99,6 +99,10 @@ int tq_set_perror_schedule(tq_env* h, int strategy, double p_start, double p_fin
  * an address range back, and does not hand out a buffer that fails the check).  Allocates, maps and synchronises; any
  * other device allocation works as `out` of tq_persp_write just as well. */
 int tq_stack_alloc(int device, uint64_t bytes, void** out);
+/* Gives the physical chunks back (synchronises the device first).  The VIRTUAL ADDRESS RANGE IS NEVER RETURNED: by
+ * design every tq_stack_alloc leaks its 2 MiB-rounded address range for the life of the process (a re-used range
+ * reaches the previous tenant's pages through stale translations on ROCm 7.2), out of a 128 TiB address space --
+ * a set-up call, not something to call per step. */
 int tq_stack_free(void* ptr);
 
 int tq_num_envs(const tq_env* h);
@@ -138,7 +142,11 @@ int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream);
 /* generatePerspectiveBatch + np.concatenate, step 2 (numba/util_actor.py:33-39): writes the
  * env-major stack out[P,2,d,d] of element type `dtype` and positions i32[P,3] (may be NULL)
  * for the offsets from tq_persp_count.  capacity = number of perspectives `out` can hold;
- * lattices that would overflow it are skipped and TQ_E_CAPACITY is latched (tq_check). */
+ * lattices that would overflow it are skipped and TQ_E_CAPACITY is latched (tq_check).
+ * `offsets` must be the scan of the lattices' CURRENT perspective counts (tq_persp_count after the last call that
+ * changed a syndrome).  The device checks it: offsets that are not (stale, shifted, all zero, decreasing, from another
+ * batch) are refused -- the kernel stores nothing outside [0, min(offsets[N], capacity)) perspectives, every wait in
+ * it is bounded, the grid drains, and TQ_E_INVALID is latched for tq_check; the handle stays usable. */
 int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positions,
                    int64_t capacity, int dtype, void* stream);
 /* The same for the lattices [first, first + count) only: `out` / `positions` receive the perspectives
@@ -150,7 +158,8 @@ int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count
 
 /* Same two steps for a batch of syndromes that does not live in a handle (the learner's
  * predictMaxOptimized, util_learner.py:48-111): states = device u8[n,2,d,d]. */
-/* set-up: size the calling device's scratch for up to n_max states of size d (allocates, synchronises) */
+/* set-up: size the calling device's scratch for up to n_max states of size d (allocates, synchronises).  The
+ * tq_states_persp_* calls share that ONE scratch per device: use them from one stream per device at a time. */
 int tq_states_reserve(int d, int n_max);
 int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, int64_t* offsets,
                           void* stream);
@@ -177,7 +186,7 @@ int tq_states_select_action(int n, const float* q_table, const int64_t* offsets,
                             float* q_values, void* stream);
 
 /* Reads and clears the calling device's error latch of the tq_states_* entry points (synchronises
- * `stream`): 0, TQ_E_ACTION or TQ_E_CAPACITY. */
+ * `stream`): 0, TQ_E_ACTION, TQ_E_CAPACITY or TQ_E_INVALID (offsets that do not belong to the states). */
 int tq_states_check(void* stream);
 
 /* predictMaxOptimized's reduction (util_learner.py:96-110): out[i] = max over the (n_i,3) slice of

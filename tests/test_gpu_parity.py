@@ -934,3 +934,106 @@ def test_chunked_buffers_never_alias(T):
         assert torch.equal(w, pat), mib
         del w, pat
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ the path that prevents a hang
+@pytest.mark.parametrize("d,dtype", [(7, torch.float32), (5, torch.uint8), (9, torch.bfloat16)])
+def test_offsets_that_do_not_belong_to_the_lattices_are_refused(T, d, dtype):
+    """tq_persp_write with an offsets array that is not the scan of the lattices' counts (shifted by one lattice, all
+    zeros, decreasing, a gap in the middle, stale after a step): the call returns, the grid drains (no wave waits
+    for ever on a commit turn that never comes), nothing is stored outside [0, offsets[N]) perspectives, tq_check
+    reports TQ_E_INVALID, and the next correct write on the same handle is bit-exact (stream_write.hpp: range check,
+    per-lattice count check, bounded waits)."""
+    import time
+    n = 5000
+    gpu, ora = make_pair(T, d, n, numpy_io=False)
+    gpu.resetAll()
+    ora.resetAll()
+    bp, bpos, bcnt, boff = O.generate_perspective_batch(ora.states)
+    _, off = gpu.perspectiveCounts()
+    good = off.clone()
+    assert np.array_equal(good.cpu().numpy(), boff)
+    P, tail = int(boff[-1]), 64
+    nq = 2 * d * d
+    sent = 0x5A if dtype == torch.uint8 else 0x5A5A
+    stack = torch.empty((P + tail, 2, d, d), dtype=dtype, device=gpu.device)
+    pos = torch.empty((P + tail, 3), dtype=torch.int32, device=gpu.device)
+    raw = stack.view(torch.uint8 if dtype == torch.uint8 else torch.int16 if dtype != torch.float32 else torch.int32)
+    half = torch.zeros_like(good)
+    half[n // 2:] = 5
+    bad_tables = {"shifted by one lattice": torch.cat([good[1:], good[-1:]]),
+                  "all zeros": torch.zeros_like(good),
+                  "decreasing": good.flip(0).contiguous(),
+                  "a gap of five perspectives in the middle": good + half}
+    for name, bad in bad_tables.items():
+        raw.fill_(sent)
+        pos.fill_(-7)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gpu.writePerspectives(stack[:P + 8], pos, bad)      # capacity P + 8 perspectives
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 5.0, name          # returned: every wait in the kernel is bounded
+        with pytest.raises(ValueError, match="offsets"):
+            gpu.check()
+        assert bool((raw[P + 8:] == sent).all()) and bool((pos[P + 8:] == -7).all()), name   # nothing behind the capacity
+        gpu.check()                                          # the latch is cleared by the read
+    # stale offsets: the lattices moved on (a step) and the old scan is handed in again
+    gpu.actorStep(None, want_actions=False)
+    gpu.writePerspectives(stack[:P], pos, good)
+    with pytest.raises(ValueError, match="offsets"):
+        gpu.check()
+    # the handle is as good as new: a correct write is bit-exact
+    oact, _, _ = O.select_action_batch(np.zeros((P, 3), np.float32), boff, bpos, 1.0, ora.seed, ora.env_ids, ora.episodes, ora.steps)
+    _, _, oterm, _ = ora.step(oact)
+    idx = np.nonzero(oterm | (ora.steps > 75))[0]
+    if idx.size:
+        ora.resetTerminalEnvs(idx)
+    per, ppos, cnt = gpu.generatePerspective(dtype=dtype)
+    bp2, bpos2, bcnt2, _ = O.generate_perspective_batch(ora.states)
+    assert np.array_equal(per.float().cpu().numpy(), bp2.astype(np.float32)) and np.array_equal(ppos.cpu().numpy(), bpos2)
+    gpu.check()
+    # an honest empty stack (no lattice has a defect) is not an error
+    gpu.setQubits(np.zeros((n, 2, d, d), np.uint8))
+    _, off0 = gpu.perspectiveCounts()
+    assert int(off0[-1]) == 0
+    gpu.writePerspectives(stack[:P], pos, off0)
+    gpu.check()
+    gpu.close()
+    # the stateless entry points refuse a foreign table as well
+    st = torch.as_tensor(ora.states.astype(np.uint8), device="cuda")
+    per, ppos, cnt, soff = T.generatePerspectiveBatch(d // 2, d, st, dtype=dtype, return_offsets=True)
+    import ctypes as C
+    L = T.load()
+    wrong = torch.cat([soff[1:], soff[-1:]]).contiguous()
+    out = torch.empty((int(soff[-1]) + 8, 2, d, d), dtype=dtype, device="cuda")
+    from toric_rl_decoder_amd.envset import _DTYPES, _ptr, _stream
+    assert L.tq_states_persp_write(d, n, _ptr(st), _ptr(wrong), _ptr(out), C.c_void_p(0), int(soff[-1]), _DTYPES[dtype], _stream()) == 0
+    assert L.tq_states_check(_stream()) == -1 and b"offsets" in L.tq_last_error()
+    assert L.tq_states_check(_stream()) == 0
+
+
+def test_scan_after_a_large_stack_leaves_no_stale_cut_points(T):
+    """One handle: a large stack, then a state with fewer perspectives than the stack write has workgroups (P < 256).
+    Every entry of the cut-point table is rewritten by every scan (k_scan_final), so the small stack is exact."""
+    d, n = 5, 6000
+    gpu, ora = make_pair(T, d, n, numpy_io=False)
+    gpu.resetAll()
+    ora.resetAll()
+    per, pos, cnt = gpu.generatePerspective()
+    bp, bpos, _, _ = O.generate_perspective_batch(ora.states)
+    assert np.array_equal(per.cpu().numpy(), bp.astype(np.float32))
+    rng = np.random.default_rng(5)
+    for hot in (1, 3, 9):                                    # lattices that keep one error: 4-8 perspectives each
+        q = np.zeros((n, 2, d, d), np.uint8)
+        where = rng.choice(n, hot, replace=False)
+        q[where, rng.integers(0, 2, hot), rng.integers(0, d, hot), rng.integers(0, d, hot)] = rng.integers(1, 4, hot)
+        gpu.setQubits(q)
+        per, pos, cnt = gpu.generatePerspective()
+        bp, bpos, bcnt, _ = O.generate_perspective_batch(O.syndrome(q))
+        assert 0 < bp.shape[0] < 256
+        assert np.array_equal(per.cpu().numpy(), bp.astype(np.float32)) and np.array_equal(pos.cpu().numpy(), bpos)
+        assert np.array_equal(cnt.cpu().numpy(), bcnt)
+        reused, rpos, _ = gpu.generatePerspectiveReused()
+        assert np.array_equal(reused.cpu().numpy(), bp.astype(np.float32)) and np.array_equal(rpos.cpu().numpy(), bpos)
+    gpu.check()
+    gpu.close()

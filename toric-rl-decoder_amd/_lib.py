@@ -67,7 +67,7 @@ class ToricEnvError(RuntimeError):
 
 def build(force=False, verbose=False):
     """Compile libtoricenv.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("toricenv.hip", "kernels.hpp", "lattice.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("toricenv.hip", "kernels.hpp", "stream_write.hpp", "lattice.hpp", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "toricenv.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:

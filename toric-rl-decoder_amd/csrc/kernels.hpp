@@ -680,17 +680,23 @@ __global__ __launch_bounds__(256) void k_scan_final(const int32_t* __restrict__ 
         if (total == 0) {                                     // empty stack: any valid table will do
             if (blockIdx.x == 0) for (int k = tid; k <= G; k += 256) split[k] = 0;
         } else {
-            if (blockIdx.x == 0 && tid == 0) split[0] = 0;
+            // kfloor(x) = the largest k with T_k = (total * k) >> LG <= x: float estimate, exact fix-up
+            auto T = [&](int64_t k) { return (int64_t)(((uint64_t)total * (uint64_t)k) >> LG); };
+            auto kfloor = [&](int64_t x) {
+                int64_t k = (int64_t)((double)(x + 1) * (double)G / (double)total);
+                k = k < 0 ? 0 : (k > G ? G : k);
+                while (k < G && T(k + 1) <= x) ++k;
+                while (k > 0 && T(k) > x) --k;
+                return k;
+            };
+            // cut points with T_k = 0 (k = 0, and k < G / total when the stack has fewer perspectives than parts) lie in
+            // no thread's interval (o[0], o[8]]: lattice 0 is their answer.  Every entry of the table is written by
+            // every scan -- nothing of an earlier, larger stack survives in it.
+            if (blockIdx.x == 0 && tid == 0) {
+                const int64_t kz = kfloor(0);
+                for (int64_t k = 0; k <= kz; ++k) split[k] = 0;
+            }
             if (o[8] > o[0]) {
-                // kfloor(x) = the largest k with T_k = (total * k) >> LG <= x: float estimate, exact fix-up
-                auto T = [&](int64_t k) { return (int64_t)(((uint64_t)total * (uint64_t)k) >> LG); };
-                auto kfloor = [&](int64_t x) {
-                    int64_t k = (int64_t)((double)(x + 1) * (double)G / (double)total);
-                    k = k < 0 ? 0 : (k > G ? G : k);
-                    while (k < G && T(k + 1) <= x) ++k;
-                    while (k > 0 && T(k) > x) --k;
-                    return k;
-                };
                 const int64_t kA = kfloor(o[0]) + 1, kB = kfloor(o[8]);
                 for (int64_t k = kA; k <= kB; ++k) {          // cut points inside (o[0], o[8]]: usually none, rarely one
                     const int64_t t = T(k);

@@ -180,6 +180,22 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
         e_hi = e_hi < e_stop ? e_hi : e_stop;
     }
     const int64_t Q0 = offsets[e_lo] - off0, Q1 = offsets[e_hi] - off0;        // perspective range [Q0, Q1)
+    // The offsets come from the caller: whatever they hold, nothing is stored outside [0, p_all) perspectives.  Offsets
+    // that are not monotone over this workgroup's cut points are refused here; offsets that do not match the lattices'
+    // own hit counts are refused by the producer that meets the first such lattice (below).
+    if (Q0 < 0 || Q1 < Q0 || Q1 > p_all) {
+        if (threadIdx.x == 0) atomicOr(err, ERR_INTERNAL);
+        return;
+    }
+    if (p_all == 0 && e_stop == e_end) {                     // "the stack is empty": true only if no lattice of the range has a hit
+        for (int64_t e = e_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += (int64_t)gridDim.x * blockDim.x) {
+            B v, pl;
+#pragma unroll
+            for (int k = 0; k < W; ++k) { v.w[k] = vp[(int64_t)k * N + e]; pl.w[k] = vp[((int64_t)W + k) * N + e]; }
+            if (L::persp_count(v, pl) != 0) atomicOr(err, ERR_INTERNAL);
+        }
+        return;
+    }
     const bool last = Q1 >= p_all;                           // no perspective behind this range
     const int64_t S0 = Q0 * NQ, S1 = Q1 * NQ;                // element range
     const int64_t org = S0 / LE * LE;                        // ring bit x <-> stack element org + x
@@ -356,6 +372,7 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
             pp[k] = in ? vp[((int64_t)W + k) * N + e_l] : 0ull;
         }
         const int64_t oo = in ? offsets[e_l] - off0 : (int64_t)0x7fffffffffffffffll;
+        const int64_t oo1 = in ? offsets[e_l + 1] - off0 : (int64_t)0x7fffffffffffffffll;
         const uint64_t inmask = __ballot(in && oo < QT);     // offsets are monotone: a prefix of the lanes
         if (!inmask) break;
         const int cnt = __popcll(inmask);
@@ -366,6 +383,9 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
             L::hit_masks(v, pl, e0, e1);
             const int n0 = e0.popc();
             const int n = n0 + e1.popc();
+            // the offsets must be the scan of THESE lattices' hit counts; a table that is not (stale, shifted, from another
+            // batch) is refused at the first lattice that disagrees, before anything of it reaches the rings
+            if (readlane64((uint64_t)oo1, j) - readlane64((uint64_t)oo, j) != (uint64_t)n) { give_up(); return; }
             if (n == 0) continue;
             const uint32_t q0 = (uint32_t)((int64_t)readlane64((uint64_t)oo, j) - Q0);
             const uint32_t bit0 = head + q0 * (uint32_t)NQ, bit1 = bit0 + (uint32_t)n * NQ;

@@ -58,9 +58,6 @@ struct DeviceCtx {
     void* ws = nullptr;             // scratch of the tq_states_persp_* entry points (tq_states_reserve)
     size_t ws_bytes = 0;
     int num_cus = 0;
-    int32_t* split = nullptr;       // cut points of the stateless stack write, written by the scan
-    const int64_t* split_for = nullptr;   // the offsets array the scan's tables were computed for
-    int split_n = 0, split_d = 0;         // ... and the batch shape
 };
 constexpr int SPLIT_LG = 8;         // 256 persistent workgroups: one per CU of an MI355X
 constexpr int SPLIT_MAX = 1 << SPLIT_LG;
@@ -79,7 +76,8 @@ int decode_latch(int flag) {
     if (flag & tq::ERR_ACTION) return fail(TQ_E_ACTION, "an action outside the lattice or with op not in 1..3 was applied");
     if (flag & tq::ERR_CAPACITY) return fail(TQ_E_CAPACITY, "perspective stack capacity exceeded");
     if (flag & tq::ERR_INTERNAL)
-        return fail(TQ_E_INVALID, "stack write gave up waiting (offsets do not belong to these lattices?)");
+        return fail(TQ_E_INVALID, "stack write refused: the offsets are not the scan of these lattices' perspective counts "
+                                  "(stale, shifted or from another batch), or a wave gave up waiting");
     if (flag & tq::ERR_INDEX) return fail(TQ_E_INDEX, "tq_reset_idx: an index outside [0, n_envs) was given");
     if (flag & tq::ERR_RESET_DUP) return fail(TQ_E_INDEX, "tq_reset_idx: an index was listed more than once");
     if (flag & tq::ERR_RESET_ROUNDS)
@@ -125,10 +123,6 @@ int get_lut(int dev, int d, hipStream_t stream, const uint16_t** out) {
     if (!c.err) {
         HIPCHECK(hipMalloc((void**)&c.err, sizeof(int)));
         HIPCHECK(hipMemset(c.err, 0, sizeof(int)));
-    }
-    if (!c.split) {
-        HIPCHECK(hipMalloc((void**)&c.split, (SPLIT_MAX + 2) * sizeof(int32_t)));
-        HIPCHECK(hipMemset(c.split, 0, (SPLIT_MAX + 2) * sizeof(int32_t)));
     }
     if (!c.num_cus) {
         hipDeviceProp_t prop;
@@ -693,9 +687,9 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-    if (int rc = launch_scan(cnt, part, false, offsets, counts, n, stream, g_ctx[dev].split)) return rc;
-    g_ctx[dev].split_for = offsets;
-    g_ctx[dev].split_n = n; g_ctx[dev].split_d = d;
+    // no cut-point table for the stateless path: a per-device table would be shared by every caller and stream of the
+    // device; the workgroups of tq_states_persp_write find their cut points themselves (find_cut, a few microseconds)
+    if (int rc = launch_scan(cnt, part, false, offsets, counts, n, stream, nullptr)) return rc;
     return TQ_OK;
 }
 
@@ -716,9 +710,7 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
     DISPATCH_D(d, CALL)
 #undef CALL
     KCHECK();
-    // cut points of the last tq_states_persp_count, if it scanned these very offsets for a batch of this shape
-    const int32_t* split = (offsets == g_ctx[dev].split_for && g_ctx[dev].split_n == n && g_ctx[dev].split_d == d) ? g_ctx[dev].split : nullptr;
-#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, err, stream, 0, n, split)) return rc
+#define CALL(D) if (int rc = launch_persp_write<D>(vp, n, offsets, out, positions, capacity, dtype, err, stream, 0, n, nullptr)) return rc
     DISPATCH_D(d, CALL)
 #undef CALL
     return TQ_OK;

@@ -179,11 +179,36 @@ def predictMaxOptimized(model, batch_state, grid_shift, system_size, device, chu
     return segment_max(q, offsets, largest)
 
 
+def _greedy_episodes(envs, model, epsilon, num_of_steps, chunk):
+    """The inner loop of evaluation.py:78-110 / results/small_p_error_test.py:131-151 for all lattices of ``envs`` side
+    by side: select (policy forward + device selection) -> step, until every lattice is solved or ``num_of_steps``
+    steps were taken.  -> dict of device tensors: done (syndrome cleared), steps per episode, sum / count of the
+    chosen action's Q-value over all live steps."""
+    n = envs.no_envs
+    done = torch.zeros(n, dtype=torch.bool, device=envs.device)
+    n_steps = torch.zeros(n, dtype=torch.int64, device=envs.device)
+    q_sum = torch.zeros((), dtype=torch.float64, device=envs.device)
+    q_cnt = torch.zeros((), dtype=torch.int64, device=envs.device)
+    for _ in range(int(num_of_steps)):
+        act, qv = selectActionEnvSet(envs, model, epsilon, chunk=chunk)    # op 0 for solved lattices
+        live = ~done
+        chosen = torch.gather(qv, 1, (act[:, 3].long() - 1).clamp(min=0).unsqueeze(1)).squeeze(1)
+        q_sum += (chosen.double() * live).sum()
+        q_cnt += live.sum()
+        n_steps += live
+        _, _, term, _ = envs.step(act)
+        done = done | term.bool()
+        if bool(done.all()):
+            break
+    return dict(done=done, n_steps=n_steps, q_sum=q_sum, q_cnt=q_cnt)
+
+
 def evaluate(model, env, env_config, grid_shift, device, prediction_list_p_error, num_of_episodes=1,
              num_actions=3, epsilon=0.0, num_of_steps=50, plot_one_episode=False, minimum_nbr_of_qubit_errors=0,
-             seed=0, chunk=1 << 16):
+             seed=0, chunk=1 << 16, round_like_reference=True):
     """evaluation.py:10-124 with the episodes of one p_error run side by side as one EnvSet.
-    -> (error_corrected_list, ground_state_list, average_number_of_steps_list, mean_q_list, failed_syndroms)."""
+    -> (error_corrected_list, ground_state_list, average_number_of_steps_list, mean_q_list, failed_syndroms).
+    ``round_like_reference=False`` leaves steps (1 decimal upstream) and mean Q (3 decimals) unrounded."""
     # like upstream, `minimum_nbr_of_qubit_errors` is accepted and unused: the sampler is chosen by
     # env_config["min_qubit_errors"] (evaluation.py:51)
     model.to(device)
@@ -199,26 +224,15 @@ def evaluate(model, env, env_config, grid_shift, device, prediction_list_p_error
         envs = EnvSet(ToricEnv(cfg, device=device, seed=seed + i), num_of_episodes, device=device, numpy_io=False)
         envs.resetAll()
         init_q = envs.getQubits().clone()
-        done = torch.zeros(num_of_episodes, dtype=torch.bool, device=envs.device)
-        n_steps = torch.zeros(num_of_episodes, dtype=torch.int64, device=envs.device)
-        q_sum = torch.zeros((), dtype=torch.float64, device=envs.device)
-        q_cnt = torch.zeros((), dtype=torch.int64, device=envs.device)
-        for _ in range(int(num_of_steps)):
-            act, qv = selectActionEnvSet(envs, model, epsilon, chunk=chunk)    # op 0 for solved lattices
-            live = ~done
-            chosen = torch.gather(qv, 1, (act[:, 3].long() - 1).clamp(min=0).unsqueeze(1)).squeeze(1)
-            q_sum += (chosen.double() * live).sum()
-            q_cnt += live.sum()
-            n_steps += live
-            _, _, term, _ = envs.step(act)
-            done = done | term.bool()
-            if bool(done.all()):
-                break
+        r = _greedy_episodes(envs, model, epsilon, num_of_steps, chunk)
+        done = r["done"]
         gs = envs.evalGroundState().bool()
         corrected[i] = float(done.double().mean())
         ground[i] = float(gs.double().mean())
-        steps_avg[i] = np.round(float(n_steps.double().mean()), 1)
-        mean_q[i] = np.round(float(q_sum / q_cnt.clamp(min=1)), 3)
+        steps_avg[i] = float(r["n_steps"].double().mean())
+        mean_q[i] = float(r["q_sum"] / r["q_cnt"].clamp(min=1))
+        if round_like_reference:
+            steps_avg[i], mean_q[i] = np.round(steps_avg[i], 1), np.round(mean_q[i], 3)
         bad = (~done) | (~gs)
         if bool(bad.any()):
             fq = envs.getQubits()[bad].cpu().numpy()
@@ -228,3 +242,93 @@ def evaluate(model, env, env_config, grid_shift, device, prediction_list_p_error
         envs.check()
         envs.close()
     return corrected, ground, steps_avg, mean_q, failed
+
+
+# ---- the forced-errors sampler of results/small_p_error_test.py (the reference's second recorded accuracy target)
+def generateRandomError(matrix, p_error, rng=np.random):
+    """results/small_p_error_test.py:22-31: depolarizing errors -- u ~ U(0,1) per qubit, error iff u < p_error,
+    Pauli = randint(3) + 1.  ``matrix``: (..., 2, d, d), only its shape is used (as upstream)."""
+    u = rng.uniform(0, 1, size=matrix.shape)
+    pauli = rng.integers(3, size=matrix.shape) + 1 if hasattr(rng, "integers") else rng.randint(3, size=matrix.shape) + 1
+    return ((u < p_error) * pauli).astype(np.int64)
+
+
+def generateNRandomErrors(matrix, n, rng=np.random):
+    """:34-40: exactly n errors on uniformly chosen distinct qubits, Pauli uniform; batched over leading axes."""
+    shape = matrix.shape
+    nq = 2 * shape[-1] * shape[-1]
+    flat = np.zeros((int(np.prod(shape[:-3], dtype=np.int64)), nq), np.int64)
+    pauli = rng.integers(3, size=(flat.shape[0], n)) + 1 if hasattr(rng, "integers") else rng.randint(3, size=(flat.shape[0], n)) + 1
+    flat[:, :n] = pauli
+    # a uniform shuffle of each row: argsort of iid uniforms
+    order = np.argsort(rng.uniform(size=flat.shape), axis=1)
+    flat = np.take_along_axis(flat, order, axis=1)
+    return flat.reshape(shape)
+
+
+def generateNPlusQRandomErrors(q, p_error, qubit_matrix, rng=np.random):
+    """:43-52: q forced errors plus depolarizing noise at p_error on the OTHER qubits.  Batched: qubit_matrix
+    (n, 2, d, d) (or (2, d, d)); only its shape is used."""
+    forced = generateNRandomErrors(np.zeros(qubit_matrix.shape, np.int64), q, rng)
+    noise = generateRandomError(np.zeros(qubit_matrix.shape), p_error, rng)
+    noise[forced != 0] = 0
+    return forced + noise
+
+
+def prediction_smart(model, env, env_config, grid_shift, device, prediction_list_p_error, num_of_episodes=1, epsilon=0.0,
+                     num_of_steps=50, plot_one_episode=False, show_network=False, show_plot=False, nbr_of_qubit_errors=0,
+                     print_Q_values=False, checkpoint=10000, seed=0, chunk=1 << 16, round_like_reference=True):
+    """results/small_p_error_test.py:55-196 with the episodes of one p_error side by side on the GPU: every episode
+    starts from ``nbr_of_qubit_errors`` forced errors plus depolarizing noise (generateNPlusQRandomErrors), redrawn
+    until the syndrome is not empty (:109-120; a stabilizer-shaped draw has none), written into the lattices with
+    ``env.qubit_matrix = ...`` (tq_set_qubits), then the greedy loop and evalGroundState.
+    -> (error_corrected_list, ground_state_list, average_number_of_steps_list, mean_q_list,
+        number_of_failed_syndroms_list, N_fail, P_l_list, failed_syndromes) as upstream."""
+    from math import comb
+    model.to(device)
+    model.eval()
+    size = int(env_config["size"])
+    if int(grid_shift) != size // 2:
+        raise ValueError("grid_shift must be int(size/2)")
+    k = len(prediction_list_p_error)
+    n_ep, q = int(num_of_episodes), int(nbr_of_qubit_errors)
+    max_err = size * size
+    ground, corrected, steps_avg, mean_q, P_l_list = (np.zeros(k) for _ in range(5))
+    failed = []
+    table = np.zeros((3, max_err))
+    table[0] = np.arange(max_err)
+    N_fail = 0.0
+    rng = np.random.default_rng(seed)
+    for i, p in enumerate(prediction_list_p_error):
+        cfg = {"size": size, "min_qubit_errors": int(env_config.get("min_qubit_errors", 0)), "p_error": float(p)}
+        envs = EnvSet(ToricEnv(cfg, device=device, seed=seed + i), n_ep, device=device, numpy_io=False)
+        qm = generateNPlusQRandomErrors(q, float(p), np.zeros((n_ep, 2, size, size), np.int64), rng)
+        for _ in range(1000):                                   # "while terminal_state": redraw the lattices without a defect
+            envs.setQubits(qm.astype(np.uint8))
+            empty = envs.isTerminal().bool().cpu().numpy()
+            if not empty.any():
+                break
+            qm[empty] = generateNPlusQRandomErrors(q, float(p), np.zeros((int(empty.sum()), 2, size, size), np.int64), rng)
+        else:
+            raise RuntimeError("the sampler kept producing empty syndromes")
+        flips = (qm != 0).reshape(n_ep, -1).sum(1)
+        r = _greedy_episodes(envs, model, epsilon, num_of_steps, chunk)
+        done = r["done"].cpu().numpy()
+        gs = envs.evalGroundState().bool().cpu().numpy()
+        inside = flips < max_err
+        np.add.at(table[2], flips[inside & ~gs], 1)
+        np.add.at(table[1], flips[inside & gs], 1)
+        failed.extend(qm[~gs])
+        n_fail = np.array([0.0 if j < q else table[2, j] / comb(j, q) for j in range(max_err)])
+        N_fail = float(n_fail.sum())
+        nq = 2 * size * size
+        P_l_list[i] = comb(nq, q) * float(p) ** q * (1 - float(p)) ** (nq - q) * N_fail / n_ep
+        corrected[i] = float(done.mean())
+        ground[i] = float(gs.mean())
+        steps_avg[i] = float(r["n_steps"].double().mean())
+        mean_q[i] = float(r["q_sum"] / r["q_cnt"].clamp(min=1))
+        if round_like_reference:
+            steps_avg[i], mean_q[i] = np.round(steps_avg[i], 1), np.round(mean_q[i], 3)
+        envs.check()
+        envs.close()
+    return corrected, ground, steps_avg, mean_q, table, N_fail, P_l_list, failed

@@ -1,0 +1,278 @@
+// Tuning harness for the stack-write kernel (stream_write.hpp), any lattice size and output type: synthetic syndromes
+// at the steady-state hit density of eps = 1 play, a handful of candidate output buffers (the rate belongs to the buffer,
+// profiles/r03_stack_write_ab.txt), and on the fastest of them a sweep over {storer, positions, producer} wave counts
+// with every configuration's output compared byte for byte with the first one's, plus the per-role wait statistics
+// (STATS instantiation) of chosen configurations.  Build here, run on the GPU box:
+//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -Iinclude -Itoric-rl-decoder_amd/csrc tools/stream_tune.hip -o tools/stream_tune
+//   tools/stream_tune <d> <dtype: f32|bf16|u8> [lattices=65536]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <random>
+#include <vector>
+
+#include "stream_write.hpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int D>
+__global__ __launch_bounds__(256) void k_counts(const uint64_t* __restrict__ vp, int32_t* __restrict__ counts, int64_t N,
+                                                int64_t* __restrict__ part256) {
+    using L = tq::Lat<D>;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int cnt = 0;
+    if (e < N) {
+        typename L::B v, p;
+        for (int k = 0; k < L::W; ++k) { v.w[k] = vp[(int64_t)k * N + e]; p.w[k] = vp[((int64_t)L::W + k) * N + e]; }
+        cnt = L::persp_count(v, p);
+        counts[e] = cnt;
+    }
+    tq::block_count_partial(cnt, part256);
+}
+
+__global__ void k_diff(const uint32_t* a, const uint32_t* b, int64_t n, unsigned long long* bad) {
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+    if (c) atomicAdd(bad, c);
+}
+
+static void* alloc_vmm(size_t bytes) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    const size_t chunk = (size_t)2 << 20;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    void* va = nullptr;
+    CK(hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0));
+    for (size_t i = 0; i < n; ++i) {
+        hipMemGenericAllocationHandle_t hnd;
+        CK(hipMemCreate(&hnd, chunk, &prop, 0));
+        CK(hipMemMap((char*)va + i * chunk, chunk, 0, hnd, 0));
+        CK(hipMemRelease(hnd));
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(va, n * chunk, &acc, 1));
+    CK(hipMemset(va, 0, n * chunk));
+    return va;
+}
+
+struct Timer {
+    hipEvent_t e0, e1;
+    Timer() { CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); }
+    template <class F> float run(F f) {
+        CK(hipEventRecord(e0)); f(); CK(hipGetLastError()); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms;
+    }
+};
+
+struct Ctx {
+    const uint64_t* vp; int64_t N; const int64_t* off; void* out; int32_t* pos; int64_t P; int* err; const int32_t* split;
+    void* ref; int32_t* pref; unsigned long long* bad; double bytes; size_t out_bytes; Timer* t;
+};
+
+template <int D, typename OutT, int NS, int NPW, int NP, int CPW, int RB, int RP>
+void one(Ctx& c, bool stats, bool is_ref) {
+    constexpr int WV = NS + NPW + NP;
+    auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, false, NPW>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
+                                      (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, c.split, (unsigned long long*)nullptr); };
+    CK(hipMemset(c.out, 0x77, c.out_bytes)); CK(hipMemset(c.pos, 0x77, (size_t)c.P * 12));
+    k(); CK(hipDeviceSynchronize());
+    unsigned long long nb = 0;
+    if (is_ref) {
+        CK(hipMemcpy(c.ref, c.out, c.out_bytes, hipMemcpyDeviceToDevice)); CK(hipMemcpy(c.pref, c.pos, (size_t)c.P * 12, hipMemcpyDeviceToDevice));
+    } else {
+        CK(hipMemset(c.bad, 0, 8));
+        hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, 0, (const uint32_t*)c.ref, (const uint32_t*)c.out, (int64_t)(c.out_bytes / 4), c.bad);
+        hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)c.pref, (const uint32_t*)c.pos, (int64_t)c.P * 3, c.bad);
+        CK(hipMemcpy(&nb, c.bad, 8, hipMemcpyDeviceToHost));
+    }
+    int e; CK(hipMemcpy(&e, c.err, 4, hipMemcpyDeviceToHost));
+    float a = 0, mn = 1e9;
+    for (int r = 0; r < 9; ++r) { float x = c.t->run(k); if (r) { a += x; mn = std::min(mn, x); } }
+    printf("  NS=%d NPW=%d NP=%2d CPW=%2d ring 2^%d/2^%d  %7.1f us  %6.0f GB/s (best %6.0f)   %s, latch %d\n", NS, NPW, NP, CPW, RB, RP, 1e3 * a / 8,
+           c.bytes / (a / 8) / 1e6, c.bytes / mn / 1e6, is_ref ? "reference of this sweep" : (nb ? "DIFFERS" : "same bytes"), e);
+    if (nb) printf("      %llu differing dwords\n", nb);
+    if (!stats) return;
+    unsigned long long* st;
+    CK(hipMalloc(&st, sizeof(unsigned long long) * 256 * WV * 4));
+    CK(hipMemset(st, 0, sizeof(unsigned long long) * 256 * WV * 4));
+    hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, true, NPW>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off, (OutT*)c.out, c.pos, c.P,
+                       c.err, (int64_t)0, c.N, c.split, st);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)256 * WV * 4);
+    CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+    auto agg = [&](int w0, int w1, const char* role, const char* a_name, const char* b_name) {
+        double tot = 0, wa = 0, wb = 0, items = 0, mx = 0; int n = 0;
+        for (int g = 0; g < 256; ++g) for (int w = w0; w < w1; ++w) {
+            const unsigned long long* o = &h[((size_t)g * WV + w) * 4];
+            if (!o[0]) continue;
+            tot += o[0]; wa += o[1]; wb += o[2]; items += o[3]; mx = std::max(mx, (double)o[0]); ++n;
+        }
+        if (n) printf("      %-10s waves %5d  alive %9.0f cyc (max %9.0f)  waiting for %s %5.1f %%  %s %5.1f %%  items/wave %7.1f  busy cyc/item %7.0f\n",
+                      role, n, tot / n, mx, a_name, 100 * wa / tot, b_name, 100 * wb / tot, items / n, (tot - wa - wb) / std::max(1.0, items));
+    };
+    agg(0, NS, "storer", "production", "-");
+    agg(NS, NS + NPW, "positions", "production", "-");
+    agg(NS + NPW, WV, "producer", "ring room", "commit turn");
+    CK(hipFree(st));
+}
+
+template <int D, typename OutT>
+int run(int64_t N, double q, const char* tname) {
+    using L = tq::Lat<D>;
+    constexpr int W = L::W, NQ = L::NQ, ES = (int)sizeof(OutT);
+    std::mt19937_64 rng(7);
+    std::vector<uint64_t> h((size_t)2 * W * N, 0);
+    std::bernoulli_distribution bit(q);
+    for (int64_t e = 0; e < N; ++e)
+        for (int pl = 0; pl < 2; ++pl)
+            for (int b = 0; b < L::DD; ++b)
+                if (bit(rng)) h[((size_t)pl * W + b / 64) * N + e] |= 1ull << (b & 63);
+    uint64_t* vp; CK(hipMalloc(&vp, h.size() * 8)); CK(hipMemcpy(vp, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    int32_t* counts; CK(hipMalloc(&counts, 4 * N + 64));
+    int64_t* part; CK(hipMalloc(&part, 8 * ((N + 255) / 256)));
+    int64_t* off; CK(hipMalloc(&off, 8 * (N + 2)));
+    int32_t* split; CK(hipMalloc(&split, 4 * 258));
+    int* err; CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
+    hipLaunchKernelGGL(k_counts<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, vp, counts, N, part);
+    hipLaunchKernelGGL(tq::k_scan_final, dim3((unsigned)((N + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK)), dim3(256), 0, 0, counts,
+                       (const int64_t*)part, off, (int32_t*)nullptr, N, split, 8);
+    CK(hipDeviceSynchronize());
+    int64_t P; CK(hipMemcpy(&P, off + N, 8, hipMemcpyDeviceToHost));
+    const double bytes = (double)P * (NQ * ES + 12) + (double)N * NQ;
+    const size_t out_bytes = ((size_t)P * NQ * ES + 4095) & ~(size_t)4095;
+    printf("d=%d %s  lattices %lld  perspectives %lld (%.1f per lattice)  algorithmic bytes %.4f GB\n", D, tname, (long long)N, (long long)P, (double)P / N, bytes / 1e9);
+    Timer t;
+    Ctx c{vp, N, off, nullptr, nullptr, P, err, split, nullptr, nullptr, nullptr, bytes, out_bytes, &t};
+    CK(hipMalloc(&c.ref, out_bytes)); CK(hipMalloc(&c.pref, (size_t)P * 12 + 4096)); CK(hipMalloc(&c.pos, (size_t)P * 12 + 4096)); CK(hipMalloc(&c.bad, 8));
+    // candidate buffers: the product configuration on each, the fastest is used for the sweep
+    constexpr int NS0 = D <= 5 ? 2 : 4, NP0 = D <= 5 ? 13 : (D >= 13 ? 7 : 11);
+    std::vector<void*> bufs;
+    for (int b = 0; b < 8; ++b) {
+        void* x;
+        if (b < 2) CK(hipMalloc(&x, out_bytes + (size_t)b * (3u << 20)));
+        else x = alloc_vmm(out_bytes + (size_t)b * (2u << 20));
+        bufs.push_back(x);
+    }
+    int best = 0; float best_ms = 1e9;
+    printf("candidate buffers (product configuration NS=%d NP=%d):", NS0, NP0);
+    for (int b = 0; b < 8; ++b) {
+        void* ob = bufs[b];
+        auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS0, NP0, 8, 14, 12>), dim3(256), dim3(64 * (NS0 + 1 + NP0)), 0, 0, vp, N, off, (OutT*)ob, c.pos, P, err,
+                                          (int64_t)0, N, (const int32_t*)split, (unsigned long long*)nullptr); };
+        float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(k); if (r) a += x; }
+        printf(" %s %.0f", b < 2 ? "hipMalloc" : "vmm", bytes / (a / 5) / 1e6);
+        if (a < best_ms) { best_ms = a; best = b; }
+    }
+    printf("  -> buffer %d\n", best);
+    c.out = bufs[best];
+#define CFG(NS, NPW, NP, CPW, STATS, REF) one<D, OutT, NS, NPW, NP, CPW, 14, 12>(c, STATS, REF);
+    if (D <= 5) {
+        CFG(2, 1, 13, 8, true, true)
+        CFG(4, 1, 11, 8, true, false)
+        CFG(4, 1, 11, 4, false, false)
+        CFG(4, 2, 10, 8, true, false)
+        CFG(3, 1, 12, 8, false, false)
+        CFG(3, 2, 11, 8, false, false)
+        CFG(2, 2, 12, 8, false, false)
+        CFG(2, 1, 13, 8, false, false)
+    } else if (D >= 13) {
+        CFG(4, 1, 7, 8, true, true)
+        CFG(4, 1, 4, 8, false, false)
+        CFG(4, 1, 3, 8, true, false)
+        CFG(4, 1, 2, 8, false, false)
+        CFG(4, 2, 3, 8, false, false)
+        CFG(4, 1, 7, 8, false, false)
+    } else {
+        CFG(4, 1, 11, 8, true, true)
+        CFG(4, 2, 10, 8, true, false)
+        CFG(4, 2, 10, 4, false, false)
+        CFG(4, 3, 9, 8, false, false)
+        CFG(4, 1, 7, 8, false, false)
+        CFG(4, 2, 6, 8, false, false)
+        CFG(3, 2, 11, 8, false, false)
+        CFG(4, 1, 11, 8, false, false)
+    }
+    return 0;
+}
+
+// f32, bf16 and u8 stacks of the same lattices written into the SAME buffers, one after the other: is a narrow stack
+// slower per byte than the f32 stack on one and the same memory?
+template <int D>
+int run_all(int64_t N, double q) {
+    using L = tq::Lat<D>;
+    constexpr int W = L::W, NQ = L::NQ;
+    std::mt19937_64 rng(7);
+    std::vector<uint64_t> h((size_t)2 * W * N, 0);
+    std::bernoulli_distribution bit(q);
+    for (int64_t e = 0; e < N; ++e)
+        for (int pl = 0; pl < 2; ++pl)
+            for (int b = 0; b < L::DD; ++b)
+                if (bit(rng)) h[((size_t)pl * W + b / 64) * N + e] |= 1ull << (b & 63);
+    uint64_t* vp; CK(hipMalloc(&vp, h.size() * 8)); CK(hipMemcpy(vp, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    int32_t* counts; CK(hipMalloc(&counts, 4 * N + 64));
+    int64_t* part; CK(hipMalloc(&part, 8 * ((N + 255) / 256)));
+    int64_t* off; CK(hipMalloc(&off, 8 * (N + 2)));
+    int32_t* split; CK(hipMalloc(&split, 4 * 258));
+    int* err; CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
+    hipLaunchKernelGGL(k_counts<D>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, vp, counts, N, part);
+    hipLaunchKernelGGL(tq::k_scan_final, dim3((unsigned)((N + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK)), dim3(256), 0, 0, counts,
+                       (const int64_t*)part, off, (int32_t*)nullptr, N, split, 8);
+    CK(hipDeviceSynchronize());
+    int64_t P; CK(hipMemcpy(&P, off + N, 8, hipMemcpyDeviceToHost));
+    int32_t* pos; CK(hipMalloc(&pos, (size_t)P * 12 + 4096));
+    const size_t out_bytes = (size_t)P * NQ * 4 + 4096;
+    printf("d=%d  lattices %lld  perspectives %lld: f32 / bf16 / u8 stacks into the same buffer, GB/s of algorithmic bytes (us)\n", D, (long long)N, (long long)P);
+    Timer t;
+    constexpr int NS0 = 4, NP1 = D >= 13 ? 3 : 11, NP2 = D >= 13 ? 3 : 10;
+    for (int b = 0; b < 8; ++b) {
+        void* ob;
+        if (b < 2) CK(hipMalloc(&ob, out_bytes + (size_t)b * (3u << 20)));
+        else ob = alloc_vmm(out_bytes + (size_t)b * (2u << 20));
+        auto kf = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS0, NP1, 8, 14, 12, false, 1>), dim3(256), dim3(64 * (NS0 + 1 + NP1)), 0, 0, vp, N, off, (float*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, (unsigned long long*)nullptr); };
+        auto kb = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, tq::bf16_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (tq::bf16_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, (unsigned long long*)nullptr); };
+        auto ku = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, uint8_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (uint8_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, (unsigned long long*)nullptr); };
+        auto km4 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 4, 0); };
+        auto km2 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 2, 0); };
+        auto km1 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ, 0); };
+        auto tm = [&](auto k) { float a = 0; for (int r = 0; r < 7; ++r) { float x = t.run(k); if (r) a += x; } return a / 6; };
+        const double by4 = (double)P * (NQ * 4 + 12) + (double)N * NQ, by2 = (double)P * (NQ * 2 + 12) + (double)N * NQ, by1 = (double)P * (NQ + 12) + (double)N * NQ;
+        const float f = tm(kf), bb = tm(kb), u = tm(ku), m4 = tm(km4), m2 = tm(km2), m1 = tm(km1);
+        printf("  buffer %d %-9s: f32 %5.0f (%6.1f)  bf16 %5.0f (%6.1f)  u8 %5.0f (%6.1f)   hipMemset of the stack bytes alone: %5.0f %5.0f %5.0f\n", b, b < 2 ? "hipMalloc" : "vmm 2 MiB",
+               by4 / f / 1e6, 1e3 * f, by2 / bb / 1e6, 1e3 * bb, by1 / u / 1e6, 1e3 * u, (double)P * NQ * 4 / m4 / 1e6, (double)P * NQ * 2 / m2 / 1e6, (double)P * NQ / m1 / 1e6);
+    }
+    return 0;
+}
+
+template <int D>
+int run_t(const char* ty, int64_t N, double q) {
+    if (!strcmp(ty, "all")) return run_all<D>(N, q);
+    if (!strcmp(ty, "f32")) return run<D, float>(N, q, ty);
+    if (!strcmp(ty, "bf16")) return run<D, tq::bf16_t>(N, q, ty);
+    if (!strcmp(ty, "u8")) return run<D, uint8_t>(N, q, ty);
+    printf("dtype must be f32, bf16 or u8\n");
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    const int d = argc > 1 ? atoi(argv[1]) : 7;
+    const char* ty = argc > 2 ? argv[2] : "f32";
+    const int64_t N = argc > 3 ? atoll(argv[3]) : 65536;
+    // defect probability per check that reproduces the steady-state perspectives per lattice of eps = 1 play
+    const double q = argc > 4 ? atof(argv[4]) : (d == 3 ? 0.42 : d == 5 ? 0.349 : d == 7 ? 0.29 : d == 9 ? 0.311 : d == 11 ? 0.26 : d == 13 ? 0.217 : 0.175);
+#ifdef TUNE_D
+    return run_t<TUNE_D>(ty, N, q);
+#else
+    if (d == 5) return run_t<5>(ty, N, q);
+    if (d == 7) return run_t<7>(ty, N, q);
+    printf("built for d = 5, 7 (or -DTUNE_D=<d>)\n");
+    return 1;
+#endif
+}

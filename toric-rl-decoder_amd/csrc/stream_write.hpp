@@ -9,9 +9,11 @@
 //   * NS storer waves do nothing but  ds_read_b32 -> shift -> bit->element expansion -> global_store_dwordx4
 //     along that range, in aligned windows of CPW KiB, and hand the ring words back zeroed;
 //   * one wave writes the positions (P,3) from a second ring (one packed dword per perspective).
-// Hand-off: `prod` (perspectives committed, in lattice order), `cons[s]` (low-water mark of storer s), `pcons`:
-// plain LDS words, release/acquire at workgroup scope, polled with s_sleep.  Every poll loop is bounded; a wave
-// that gives up raises `abort` for its workgroup and latches ERR_INTERNAL, so the grid always drains.
+// Hand-off: `pq[p]` (producer p: first perspective of the lattice it is working on -- its earlier lattices are in the
+// rings; the minimum over the producers is the produced PREFIX of the range, no producer ever waits for another),
+// `cons[s]` (low-water mark of storer s), `pcons[w]` (of positions wave w): plain LDS words, polled with s_sleep.
+// Every poll loop is bounded; a wave that gives up raises `abort` for its workgroup and latches ERR_INTERNAL, so the
+// grid always drains.
 //
 // Output lines: the stack is cut into 128-byte lines and a workgroup stores the lines whose FIRST element lies
 // in its range, whole.  The trailing elements of its last line belong to the first lattice(s) of the next
@@ -67,14 +69,16 @@ struct ProdTables {                                            // private to one
     uint32_t hpos[NQP];                                        // k-th hit -> layer | row << 8 | col << 16
 };
 
-template <int D, int NS, int NP, int RB_LOG, int RP_LOG>
+template <int D, int NS, int NP, int RB_LOG, int RP_LOG, int NPW = 1>
 struct StreamLds {
     __attribute__((aligned(16))) uint32_t bits[1u << RB_LOG];  // the output range as a bit string, ring
     uint32_t posr[1u << RP_LOG];                               // packed position of perspective q at [q & mask]
     ProdTables<D> tab[NP];
-    uint32_t prod;                                             // perspectives committed so far (range-relative)
+    uint32_t pq[NP];                                           // producer p: first perspective (range-relative) of the lattice it is
+                                                               // working on; everything of ITS lattices below that is in the rings;
+                                                               // 0xFFFFFFFF = it has no lattice left
     uint32_t cons[NS];                                         // storer s: first element (from org) it has not taken yet
-    uint32_t pcons;                                            // perspectives whose positions are written
+    uint32_t pcons[NPW];                                       // positions wave w: first perspective whose position it has not written yet
     uint32_t abort;
 };
 
@@ -116,8 +120,9 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offse
 
 // STATS (diagnostic builds only, tools/stream_bench.hip): every wave leaves {cycles alive, cycles waiting (A), cycles
 // waiting (B), items} in stats[(block * waves + wave) * 4 ..]; A/B = storers: production / -, producers: ring room / commit turn.
-template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false>
-__global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint64_t* __restrict__ vp, int64_t N,
+// NPW: positions waves (chunks of 1 KiB dealt round-robin among them)
+template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false, int NPW = 1>
+__global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uint64_t* __restrict__ vp, int64_t N,
                                                                   const int64_t* __restrict__ offsets, OutT* __restrict__ out,
                                                                   int32_t* __restrict__ pos, int64_t capacity,
                                                                   int* __restrict__ err, int64_t e_begin, int64_t e_end,
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
     if (STATS) t_begin = __builtin_readcyclecounter();
     auto stats_out = [&](int wv, int ln) {
         if (STATS && ln == 0) {
-            unsigned long long* o = stats + ((size_t)blockIdx.x * (NS + 1 + NP) + wv) * 4;
+            unsigned long long* o = stats + ((size_t)blockIdx.x * (NS + NPW + NP) + wv) * 4;
             o[0] = __builtin_readcyclecounter() - t_begin; o[1] = t_a; o[2] = t_b; o[3] = n_items;
         }
     };
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
     constexpr uint32_t RP = 1u << RP_LOG, PMASK = RP - 1u;
     static_assert((uint32_t)NQ * NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS, "bit ring too small for this lattice size");
     static_assert((uint32_t)NQ + 512u < RP, "position ring too small");
-    __shared__ StreamLds<D, NS, NP, RB_LOG, RP_LOG> S;
+    __shared__ StreamLds<D, NS, NP, RB_LOG, RP_LOG, NPW> S;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
@@ -223,7 +228,9 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
 
     // ---- ring and hand-off words
     for (uint32_t i = threadIdx.x; i < (1u << RB_LOG) / 4; i += blockDim.x) reinterpret_cast<uint4*>(S.bits)[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (threadIdx.x == 0) { S.prod = 0u; S.pcons = 0u; S.abort = 0u; }
+    if (threadIdx.x == 0) S.abort = 0u;
+    if (threadIdx.x < NP) S.pq[threadIdx.x] = 0u;
+    if (threadIdx.x < NPW) S.pcons[threadIdx.x] = 0u;
     if (threadIdx.x < NS) S.cons[threadIdx.x] = a0;
     __syncthreads();
 
@@ -231,6 +238,20 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
     auto give_up = [&]() {
         if (lane == 0) { __hip_atomic_store(&S.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(err, ERR_INTERNAL); }
     };
+
+    // Perspectives [0, produced()) of the range are complete in the rings: lattices are dealt to the producers round-robin
+    // and every producer works through its own in order, so every lattice that starts below the smallest `pq` is done.
+    // One LDS read by NP lanes, the minimum on the scalar unit; wave-uniform.  0xFFFFFFFF = everything.
+    auto produced = [&]() -> uint32_t {
+        uint32_t v = 0xFFFFFFFFu;
+        if (lane < NP) v = __hip_atomic_load(&S.pq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int l = 0; l < NP; ++l) { const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, l); m = x < m ? x : m; }
+        return m;
+    };
+    // stream bit position (from org) up to which the stack is produced, saturating
+    auto produced_bits = [&](uint32_t pr) -> uint32_t { return pr == 0xFFFFFFFFu ? 0xFFFFFFFFu : head + pr * (uint32_t)NQ; };
 
     if (wave < NS) {
         // =========================================================== stack storer
@@ -244,20 +265,20 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
         const int sh = (int)((a0 + lane_el) & 31u);          // a0 is a multiple of LE, EPC of 32: loop-invariant
         const bool zero_lane = (lane % LPD) == 0;
         char* __restrict__ obase = reinterpret_cast<char*>(out + org);
-        uint32_t prod_c = 0;                                 // cached S.prod
+        uint32_t prod_c = 0;                                 // cached produced()
         bool first = true;
         for (uint32_t w = (uint32_t)s; w * CPW < nchunks; w += NS) {
             for (uint32_t cb = w * CPW; cb < (w + 1) * CPW && cb < nchunks; cb += U) {
                 const uint32_t el0 = a0 + cb * EPC;
                 uint32_t end = el0 + U * EPC;
                 end = end < a1 ? end : a1;
-                if (head + prod_c * (uint32_t)NQ < end) {     // wait until the trip's last element is produced
+                if (produced_bits(prod_c) < end) {           // wait until the trip's last element is produced
                     bool ok = false;
                     unsigned long long t0 = 0;
                     if (STATS) t0 = __builtin_readcyclecounter();
                     for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
-                        prod_c = lds_peek(S.prod);
-                        if (head + prod_c * (uint32_t)NQ >= end) { ok = true; break; }
+                        prod_c = produced();
+                        if (produced_bits(prod_c) >= end) { ok = true; break; }
                         if (lds_peek(S.abort)) return;
                         __builtin_amdgcn_s_sleep(4);
                     }
@@ -314,12 +335,13 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
         return;
     }
 
-    if (wave == NS) {
-        // =========================================================== positions storer
+    if (wave < NS + NPW) {
+        // =========================================================== positions storer (1 KiB chunks, round-robin over NPW waves)
+        const int pw = wave - NS;
         if (!has_pos) return;
         int32_t* __restrict__ pbase = pos + porg;
         const uint32_t nchunks = (pa1 - pa0 + 255u) / 256u;
-        for (uint32_t c = 0; c < nchunks; ++c) {
+        for (uint32_t c = (uint32_t)pw; c < nchunks; c += NPW) {
             const uint32_t x0 = pa0 + c * 256u;
             const uint32_t x_end = x0 + 256u < pa1 ? x0 + 256u : pa1;
             const uint32_t need = (x_end - phead + 2u) / 3u;
@@ -327,9 +349,9 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
             unsigned long long t0 = 0;
             if (STATS) { t0 = __builtin_readcyclecounter(); ++n_items; }
             for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
-                if (lds_peek(S.prod) >= need) { ok = true; break; }
+                if (produced() >= need) { ok = true; break; }
                 if (lds_peek(S.abort)) return;
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(NPW > 1 ? 8 : 16);
             }
             if (!ok) { give_up(); return; }
             lds_after_peek();
@@ -345,14 +367,17 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
                 if (x + 4u <= x_end) *reinterpret_cast<int4*>(pbase + x) = make_int4(o[0], o[1], o[2], o[3]);
                 else for (uint32_t j = 0; x + j < x_end; ++j) pbase[x + j] = o[j];
             }
-            lds_publish(S.pcons, (x_end - phead) / 3u, lane);
+            // low-water mark: the first perspective of this wave's NEXT chunk (everything below it, of this wave's, is written)
+            const uint32_t nc = c + NPW;
+            lds_publish(S.pcons[pw], nc < nchunks ? (pa0 + nc * 256u - phead) / 3u : 0xFFFFFFFFu, lane);
         }
+        lds_publish(S.pcons[pw], 0xFFFFFFFFu, lane);
         stats_out(wave, lane);
         return;
     }
 
     // =============================================================== producer
-    const int p = wave - NS - 1;
+    const int p = wave - NS - NPW;
     ProdTables<D>& T = S.tab[p];
     if (lane < D) {                                          // column masks: the same for every lattice
         const B m = L::lowcols(lane);
@@ -389,10 +414,12 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
             if (n == 0) continue;
             const uint32_t q0 = (uint32_t)((int64_t)readlane64((uint64_t)oo, j) - Q0);
             const uint32_t bit0 = head + q0 * (uint32_t)NQ, bit1 = bit0 + (uint32_t)n * NQ;
+            // this wave's earlier lattices are in the rings (its LDS operations execute in issue order): say so
+            lds_publish(S.pq[p], q0, lane);
             // ---- room in the rings: everything below the storers' low-water mark has been handed back.  The marks
             // are cached: while the storers keep up the ring is nearly empty and one look lasts for dozens of lattices.
             if (STATS) ++n_items;
-            if (!((lw_c == 0xFFFFFFFFu || bit1 + 64u <= lw_c + RING_BITS) && (!has_pos || q0 + (uint32_t)n <= pc_c + RP))) {
+            if (!((lw_c == 0xFFFFFFFFu || bit1 + 64u <= lw_c + RING_BITS) && (!has_pos || pc_c == 0xFFFFFFFFu || q0 + (uint32_t)n <= pc_c + RP))) {
                 bool ok = false;
                 unsigned long long t0 = 0;
                 if (STATS) t0 = __builtin_readcyclecounter();
@@ -402,8 +429,14 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
 #pragma unroll
                     for (int o = 1; o < NS; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)c, o, 64); c = t < c ? t : c; }
                     lw_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                    pc_c = has_pos ? lds_peek(S.pcons) : 0u;
-                    if ((lw_c == 0xFFFFFFFFu || bit1 + 64u <= lw_c + RING_BITS) && (!has_pos || q0 + (uint32_t)n <= pc_c + RP)) { ok = true; break; }
+                    if (has_pos) {
+                        uint32_t pc = 0xFFFFFFFFu;
+                        if (lane < NPW) pc = __hip_atomic_load(&S.pcons[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                        for (int o = 1; o < NPW; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)pc, o, 64); pc = t < pc ? t : pc; }
+                        pc_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc);
+                    }
+                    if ((lw_c == 0xFFFFFFFFu || bit1 + 64u <= lw_c + RING_BITS) && (!has_pos || pc_c == 0xFFFFFFFFu || q0 + (uint32_t)n <= pc_c + RP)) { ok = true; break; }
                     if (lds_peek(S.abort)) return;
                     __builtin_amdgcn_s_sleep(8);
                 }
@@ -454,24 +487,11 @@ __global__ __launch_bounds__(64 * (NS + 1 + NP)) void k_persp_stream(const uint6
                 if (has_stack)
                     emit_at<D>(bit0 + (uint32_t)k * NQ, ov, op, [&](uint32_t idx, uint32_t val) { atomicOr(&S.bits[idx & BMASK], val); });
             }
-            // ---- commit in lattice order
-            {
-                bool ok = false;
-                unsigned long long t0 = 0;
-                if (STATS) t0 = __builtin_readcyclecounter();
-                for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
-                    if (lds_peek(S.prod) == q0) { ok = true; break; }
-                    if (lds_peek(S.abort)) return;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (!ok) { give_up(); return; }
-                if (STATS) t_b += __builtin_readcyclecounter() - t0;
-                lds_publish(S.prod, q0 + (uint32_t)n, lane);
-            }
             wave_lds_sync();                                 // T is rewritten by the next lattice
         }
         if (cnt < 64) break;
     }
+    lds_publish(S.pq[p], 0xFFFFFFFFu, lane);                 // no lattice left: everything of this wave is in the rings
     stats_out(wave, lane);
 }
 

@@ -146,20 +146,32 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
 }
 
 // The stack write (stream_write.hpp): SPLIT_MAX persistent workgroups, one per CU, each with its own contiguous
-// part of the stack.  Storer / producer waves per workgroup: the storers saturate a CU's store path with 2-4 waves
-// and the producers idle 80-90 % of the time for d >= 7 (profiles/r03_stack_write_ab.txt), but small lattices are
-// producer-bound (a d=3 lattice is 0.8 KB of output against a fixed set-up), so they get every wave that is left.
+// part of the stack.  Waves per workgroup by role, from the sweeps of tools/stream_tune.hip (profiles/r04_stream_tune_*):
+//   * storers: 4 saturate a CU's store path (2 for d <= 5, whose short rows leave the producers more to do);
+//   * positions waves: 1 for a 4-byte stack; 2 for 16- and 8-bit stacks, which carry 2-4 times the perspectives per
+//     byte stored (u8, d=7: 5.3 -> 6.0-6.2 TB/s);
+//   * producers: whatever the stack needs and NOT more -- idle producers poll and cost the storers issue slots.
+//     d >= 13 (3-4 words per plane, some spilling): 3 producers write a f32 stack faster (6.9 TB/s) than 7 (6.4);
+//     narrow stacks there need the 7.  Small lattices are producer-bound (a d=3 lattice is 1.3 KB of output against
+//     ~3000 cycles of set-up), so d <= 5 gets every wave that is left.
+template <int D, int ES>
+struct StreamCfg {
+    static constexpr int NS = D <= 5 ? 2 : 4;
+    static constexpr int NPW = ES < 4 ? (D >= 13 ? 1 : 2) : 1;
+    static constexpr int NP = D >= 13 ? (ES == 4 ? 3 : 7) : 16 - NS - NPW;
+    static constexpr int CPW = 8, RB = 14, RP = 12;          // 8 KiB windows, 64 KB bit ring, 16 KB position ring
+};
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, int* err, hipStream_t stream, int64_t first, int64_t count,
                          const int32_t* split) {
-    constexpr int NS = D <= 5 ? 2 : 4, NP = D <= 5 ? 13 : (D >= 13 ? 7 : 11), CPW = 8;
-    constexpr int RB = 14, RP = 12;                            // 64 KB bit ring, 16 KB position ring
+    using C = StreamCfg<D, (int)sizeof(OutT)>;
     // a workgroup's part of the stack is addressed with 32-bit element offsets
     if ((double)count * (2.0 * D * D) * (2.0 * D * D) / SPLIT_MAX > 2.0e9)
         return fail(TQ_E_INVALID, "lattice range too large for one stack write (%lld lattices of d=%d)", (long long)count, D);
-    hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP>), dim3(SPLIT_MAX), dim3(64 * (NS + 1 + NP)), 0, stream,
-                       vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, C::NS, C::NP, C::CPW, C::RB, C::RP, false, C::NPW>), dim3(SPLIT_MAX),
+                       dim3(64 * (C::NS + C::NPW + C::NP)), 0, stream, vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split,
+                       (unsigned long long*)nullptr);
     KCHECK();
     return TQ_OK;
 }

@@ -38,6 +38,7 @@ import socket
 import subprocess
 import sys
 import time
+import types
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes), before HIP initialises
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")             # NN_11 leg: no exhaustive solver search on a fresh box
@@ -88,10 +89,6 @@ def parse(argv=None):
                     help="stack buffers to allocate at set-up; the one the write kernel is fastest on is kept, the others are "
                          "freed (the write rate depends on the buffer: 5.1-5.5 TB/s into a plain allocation, 6.5-6.8 into most "
                          "tq_stack_alloc buffers on most boxes, profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")
-    ap.add_argument("--stack-good-enough", type=float, default=0.80,
-                    help="the probe stops early at a candidate whose write takes less than this fraction of candidate 0's "
-                         "(well-placed buffers take 0.79-0.83 of a plain allocation's time and differ by ~2 %% among themselves: "
-                         "the default tries nearly always all candidates, ~1 s of set-up)")
     ap.add_argument("--stack-kinds", default="torch,chunked",
                     help="where the candidates come from (first entry: candidate 0, the rest cyclically for the others): torch = "
                          "torch.empty, chunked = T.alloc_stack (2 MiB physical "
@@ -104,6 +101,11 @@ def parse(argv=None):
                     help="N=1: skip the extra timing of the N>1 per-GPU shape (131072 lattices); profiling runs use this "
                          "so that every k_persp_stream launch of the process has the headline shape")
     ap.add_argument("--no-events", action="store_true", help="no per-launch HIP events (pure wall clock)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="default path: run the fused step and the scan BEHIND the stack write on one stream (the reference's order) "
+                         "instead of beside it on a second stream (T.ExploreLoop)")
+    ap.add_argument("--bf16-steps", type=int, default=20,
+                    help="N=1: timed steps of the bf16-stack leg (the stack the bf16 nn_in_loop variant consumes), with its own roofline; 0 = skip")
     ap.add_argument("--graph", action="store_true",
                     help="capture --flush steps in a HIP graph and replay it (launch-bound small batches; implies "
                          "--no-events: no per-launch timing inside a graph, so no roofline object)")
@@ -244,91 +246,187 @@ def cpu_baseline(d, p, seed, budget_s):
 
 
 class Shard:
-    """One sub-shard of this GPU's lattices with its stream and its caller-owned output buffers."""
+    """One sub-shard of this GPU's lattices with its stream and its caller-owned output buffers (legacy serial path:
+    --shards > 1, --graph, --policy nn11)."""
 
 
-def time_plain_loop(T, torch, env, n, d, seed, first, tdtype, flush, device, steps, warm, chunks=1, events=False, candidates=1,
-                    kinds=("torch", "chunked"), event_every=4, good_enough=0.80):
-    """The same pass over a batch of `n` lattices on the current stream, no collective: burn-in, `warm` untimed
-    and `steps` timed steps.  -> (seconds, perspectives in the timed steps, per-step stack-write milliseconds
-    from HIP events or None).  Used at N=1 for the extra legs of the line: one GPU on the per-GPU shape of the
-    N>1 runs (configs[4]: 131 072 lattices) and BASELINE configs[3] (65 536 lattices, d=9, p=0.15), one shot
-    and with the stack written in `chunks` lattice ranges into a buffer of 1/chunks the size."""
-    nq = 2 * d * d
-    envs = T.EnvSet(env, n, device=device, seed=seed, first_env_id=first, numpy_io=False)
-    envs.resetAll()
-    stack = torch.empty(((n // chunks) * nq, 2, d, d), dtype=tdtype, device=device)
-    positions = torch.empty(((n // chunks) * nq, 3), dtype=torch.int32, device=device)
-    offs = torch.zeros((warm + steps, (n + 2) & ~1), dtype=torch.int64, device=device)
-    blocks = [envs.newTransitionBlock(steps=flush) for _ in range(2)]
-    every = max(1, min(int(event_every), steps))
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range((steps + every - 1) // every)] if events else None
-    for t in range(EPISODE):
-        idx = torch.arange(t, n, EPISODE, dtype=torch.int32, device=device)
-        if idx.numel():
-            envs.resetTerminalEnvs(idx)
-        envs.actorStep(None, want_actions=False)
-    probe = None
-    if candidates > 1:                                               # placement probe, as in the main loop
-        del stack
+def hbm_roofline(alg_bytes, write_ms, extra=None):
+    """The `roofline` object of one leg: algorithmic bytes per launch over the stack write's average
+    duration from HIP events on the stream the kernel runs on."""
+    ms = float(np.mean(write_ms))
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": STACK_KERNEL, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+         "bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "median_launch_ms": float(np.median(write_ms)), "launches_timed": int(np.size(write_ms))}
+    if extra:
+        r.update(extra)
+    return r
+
+
+class ExploreLeg:
+    """One timed leg of the eps = 1 actor loop on `n` lattices of this GPU through T.ExploreLoop: lattices, burn-in
+    (episodes staggered: lattice e is reset at step e mod 76), the caller-owned buffers, the stack-buffer probe (in
+    the loop, all candidates allocated first), warm-up with a check of the probe's prediction (one bounded re-probe),
+    the timed steps, the byte-for-byte verification of the timed buffer and the leg's own `roofline`."""
+
+    def __init__(self, T, torch, env, n, d, seed, first, tdtype, flush, device, rows, chunks=1, overlap=True, transitions=True,
+                 burn_in=True, on_flush=None):
+        self.T, self.torch, self.n, self.d, self.device, self.tdtype, self.chunks, self.flush = T, torch, n, d, device, tdtype, chunks, flush
+        self.nq = 2 * d * d
+        self.esize = torch.empty((), dtype=tdtype).element_size()
+        self.envs = T.EnvSet(env, n, device=device, seed=seed, first_env_id=first, numpy_io=False)
+        self.envs.resetAll()
+        self.cap = (n // chunks) * self.nq      # worst case every qubit is a hit: 2.5 GB at d=7 f32, 6.9 GB at d=9 for 65 536 lattices
+        self.stack = torch.empty((self.cap, 2, d, d), dtype=tdtype, device=device)
+        self.positions = torch.empty((self.cap, 3), dtype=torch.int32, device=device)
+        self.offs = torch.zeros((rows, (n + 2) & ~1), dtype=torch.int64, device=device)     # one scan per step: P = row[n]
+        self.blocks = [self.envs.newTransitionBlock(steps=flush) for _ in range(2)] if transitions else None
+        if burn_in:
+            for t in range(EPISODE):
+                idx = torch.arange(t, n, EPISODE, dtype=torch.int32, device=device)
+                if idx.numel():
+                    self.envs.resetTerminalEnvs(idx)
+                self.envs.actorStep(None, want_actions=False)
+        torch.cuda.synchronize(device)
+        self.loop = T.ExploreLoop(self.envs, self.stack, self.positions, self.offs, blocks=self.blocks, flush=flush, chunks=chunks,
+                                  overlap=overlap, on_flush=on_flush)
+        self.probe = None
+        self.ev, self.t0, self.K, self.every = [], 0, 0, 1
+
+    def pick_stack(self, candidates, kinds):
+        """Set-up, untimed: the stack buffer is re-used every step, so its placement is chosen by timing the write, inside
+        the loop, on every candidate (EnvSet.pickStackBuffer with ExploreLoop.time_writes)."""
+        torch = self.torch
+        if candidates <= 1 and kinds[0] == "torch":
+            return
+        del self.stack
+        self.loop.stack = None
         torch.cuda.empty_cache()
-        if chunks == 1:
-            stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, positions=positions, kinds=kinds, park=True, good_enough=good_enough)
-        else:                                                        # the small buffer of the range-by-range consumer, probed with the first range
-            stack, probe = envs.pickStackBuffer(candidates, dtype=tdtype, capacity=(n // chunks) * nq, positions=positions, kinds=kinds,
-                                                park=True, first=0, count=n // chunks, good_enough=good_enough)
+        time.sleep(0.3)                         # the driver wipes freed memory in the background
+        self.stack, self.probe = self.envs.pickStackBuffer(candidates, dtype=self.tdtype, capacity=self.cap, positions=self.positions, kinds=kinds,
+                                                           park=True, timer=self.loop.time_writes, launches=10, passes=2)
+        self.loop.stack = self.stack
+        self.probe["note"] = ("set-up, untimed (EnvSet.pickStackBuffer): every candidate allocated first, then the stack write timed INSIDE the "
+                              "loop (HIP events around the write, the env kernels beside it) on each candidate in two passes of 5 writes; the "
+                              "median decides; candidate 0 is the allocation a caller gets by default (torch.empty), the others T.alloc_stack "
+                              "= tq_stack_alloc (2 MiB physical chunks); rejected candidates stay parked until the timed region is over")
 
-    def step(t):
-        off = offs[t][:n + 1]
-        envs.perspectiveCounts(off)
-        timed = ev is not None and t >= warm and (t - warm) % every == 0
-        if timed:
-            ev[(t - warm) // every][0].record()
-        if chunks == 1:
-            envs.writePerspectives(stack, positions, off)
-        else:
-            for c in range(chunks):
-                envs.writePerspectives(stack, positions, off, first=c * (n // chunks), count=n // chunks)
-        if timed:
-            ev[(t - warm) // every][1].record()
-        blk = blocks[(t // flush) & 1]
-        envs.actorStep(None, block=blk, slot=t % flush, want_actions=True)
-        if (t + 1) % flush == 0:
-            blk.computePriorities(n, flush, None, 0.95)
+    def warm(self, W, reprobe=True):
+        """W untimed steps; the last ones' writes are timed and held against the probe: more than 8 % slower -> ONE
+        re-probe among the candidates that are still parked, a few more untimed steps."""
+        torch = self.torch
+        k = min(max(W, 1), 8)
+        for _ in range(max(0, W - k)):
+            self.loop.step()
+        ms = self.loop.time_writes(self.stack, k, skip=0)
+        out = {"warm_write_ms": float(np.mean(ms))}
+        if self.probe is not None and reprobe:
+            p = self.probe["probe_ms_chosen"]
+            out["warm_over_probe"] = out["warm_write_ms"] / p
+            parked = list(getattr(self.envs, "_parked", []))
+            if out["warm_over_probe"] > 1.08 and parked:
+                self.stack, rep = self.envs.pickStackBuffer(among=[self.stack] + parked, dtype=self.tdtype, capacity=self.cap, positions=self.positions,
+                                                            park=True, timer=self.loop.time_writes, launches=10, passes=2)
+                self.loop.stack = self.stack
+                self.probe["reprobe"] = {"why": "the warm-up's writes ran %.1f %% slower than the probe predicted" % (100 * (out["warm_over_probe"] - 1)),
+                                         "write_ms": rep["write_ms"], "chosen": rep["chosen"], "probe_ms_chosen": rep["probe_ms_chosen"]}
+                self.probe["probe_ms_chosen"] = rep["probe_ms_chosen"]
+                ms = self.loop.time_writes(self.stack, 4, skip=1)
+                out["warm_write_ms_after_reprobe"] = float(np.mean(ms))
+        self.loop.drain()
+        torch.cuda.synchronize(self.device)
+        return out
 
-    for t in range(warm):
-        step(t)
+    def run(self, K, every):
+        """K steps; HIP events around every `every`-th stack write.  No synchronisation (the caller brackets)."""
+        torch = self.torch
+        self.K, self.every, self.t0 = K, max(1, min(every, K)), self.loop.t
+        assert self.offs.shape[0] > K + 1, "one offsets row per timed step"
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((K + self.every - 1) // self.every)]
+        for i in range(K):
+            self.loop.step(self.ev[i // self.every] if i % self.every == 0 else None)
+        self.loop.drain()
+
+    def perspectives(self):
+        """(P of every timed step, f64 tensor; mean P of the bracketed steps)."""
+        R = self.offs.shape[0]
+        rows = self.torch.tensor([(self.t0 + i) % R for i in range(self.K)], device=self.device)
+        p = self.offs[rows, self.n].to(self.torch.float64)
+        return p, float(p[::self.every].mean().item())
+
+    def write_ms(self):
+        return np.array([a.elapsed_time(b) for a, b in self.ev])
+
+    def roofline(self, extra=None):
+        _, p_mean = self.perspectives()
+        alg = p_mean * (self.nq * self.esize + 12) + self.n * self.nq       # SURVEY 8(d): P*(B_p+12) + N*2d^2, per step
+        ms = self.write_ms()
+        r = hbm_roofline(alg, ms, {"perspectives_per_launch": p_mean / self.chunks, "launches_per_step": self.chunks,
+                                   "lattices_per_launch": self.n // self.chunks, "bytes_per_step": alg,
+                                   "timed_launches": "HIP events on the write's stream around the stack write(s) of every %d. timed step%s" % (
+                                       self.every, "" if self.chunks == 1 else ": the %d range launches and their gaps included" % self.chunks)})
+        if self.chunks > 1:
+            r["bytes_per_launch"] = alg / self.chunks
+        if self.probe is not None:
+            r["probe_ms_chosen"] = self.probe["probe_ms_chosen"]
+            r["timed_write_ms"] = float(ms.mean())
+            r["timed_over_probe"] = float(ms.mean()) / self.probe["probe_ms_chosen"]
+            r["default_buffer"] = {"kind": self.probe["kinds"][0], "write_ms": self.probe["write_ms"][0],
+                                   "frac": r["frac"] * float(ms.mean()) / self.probe["write_ms"][0],
+                                   "note": "candidate 0 of the probe: what a caller gets without pickStackBuffer (same loop, probe's clock)"}
+        if extra:
+            r.update(extra)
+        return r
+
+    def verify(self):
+        """The buffer that was timed holds the right bytes: the stack of the current lattices written into it and into a
+        fresh torch.empty buffer, compared byte for byte (untimed).  Not a formality: a buffer reached through stale
+        address translations takes writes at 7 TB/s and is wrong in 70 % of its elements (profiles/r03_stack_write_ab.txt 12)."""
+        torch, envs, n, d = self.torch, self.envs, self.n, self.d
+        torch.cuda.synchronize(self.device)
+        off_v = self.offs[0][:n + 1]
+        envs.perspectiveCounts(off_v)
+        first_v, count_v = (0, n) if self.chunks == 1 else ((self.chunks - 1) * (n // self.chunks), n // self.chunks)
+        Pv = int((off_v[first_v + count_v] - off_v[first_v]).item())
+        ref_s = torch.empty((Pv, 2, d, d), dtype=self.tdtype, device=self.device)
+        ref_p = torch.empty((Pv, 3), dtype=torch.int32, device=self.device)
+        envs.writePerspectives(ref_s, ref_p, off_v, first=first_v, count=count_v)
+        self.stack.view(torch.uint8).fill_(0x5A)
+        envs.writePerspectives(self.stack, self.positions, off_v, first=first_v, count=count_v)
+        torch.cuda.synchronize(self.device)
+        wrong = int((self.stack[:Pv].view(torch.uint8) != ref_s.view(torch.uint8)).sum().item()) + int((self.positions[:Pv] != ref_p).sum().item())
+        return {"ok": wrong == 0, "wrong_bytes": wrong, "perspectives": Pv,
+                "how": "after the timed region: stack + positions of the current lattices written into the timed buffer and into "
+                       "a fresh torch.empty buffer, compared byte for byte"}
+
+    def close(self):
+        self.envs.check()
+        self.envs.close()                       # frees the parked candidates of the probe as well ...
+        self.loop = None
+        self.stack = None
+        self.torch.cuda.empty_cache()
+        time.sleep(0.5)                         # ... and the driver wipes freed memory in the background
+
+
+def time_explore_leg(T, torch, env, n, d, seed, tdtype, flush, device, steps, warm, chunks=1, candidates=1, kinds=("torch", "chunked"),
+                     event_every=4, overlap=True):
+    """An extra leg of the N=1 line on its own lattices, no collective: -> dict with value, ms_per_step, perspectives/s,
+    the probe's report, `stack_verified` and the leg's own `roofline` (probe_ms_chosen vs timed_write_ms included)."""
+    leg = ExploreLeg(T, torch, env, n, d, seed, 0, tdtype, flush, device, rows=steps + 4, chunks=chunks, overlap=overlap)
+    leg.pick_stack(candidates, kinds)
+    w = leg.warm(warm)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for t in range(warm, warm + steps):
-        step(t)
+    leg.run(steps, event_every)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    P = float(offs[warm:, n].sum().item())
-    # the timed buffer holds the right bytes (see main): whole batch, or the last range of the range-by-range consumer
-    off_v = offs[0][:n + 1]
-    envs.perspectiveCounts(off_v)
-    first_v, count_v = (0, n) if chunks == 1 else ((chunks - 1) * (n // chunks), n // chunks)
-    Pv = int((off_v[first_v + count_v] - off_v[first_v]).item())
-    ref_s = torch.empty((Pv, 2, d, d), dtype=tdtype, device=device)
-    ref_p = torch.empty((Pv, 3), dtype=torch.int32, device=device)
-    envs.writePerspectives(ref_s, ref_p, off_v, first=first_v, count=count_v)
-    stack.view(torch.uint8).fill_(0x5A)
-    envs.writePerspectives(stack, positions, off_v, first=first_v, count=count_v)
-    torch.cuda.synchronize(device)
-    wrong = int((stack[:Pv].view(torch.uint8) != ref_s.view(torch.uint8)).sum().item()) + int((positions[:Pv] != ref_p).sum().item())
-    time_plain_loop.last_verified = {"ok": wrong == 0, "wrong_bytes": wrong, "perspectives": Pv}
-    del ref_s, ref_p
-    time_plain_loop.last_p_bracketed = float(offs[warm::every, n].double().mean().item())   # per step, of the steps the events bracket
-    envs.check()
-    envs.close()                                                    # frees the parked candidates of the probe as well ...
-    del stack
-    torch.cuda.empty_cache()
-    time.sleep(0.5)                                                 # ... and the driver wipes freed memory in the background
-    ev_ms = np.array([a.elapsed_time(b) for a, b in ev]) if ev is not None else None
-    time_plain_loop.last_probe = probe
-    return dt, P, ev_ms
+    p_all, _ = leg.perspectives()
+    P = float(p_all.sum().item())
+    out = {"lattices": n, "d": d, "steps": steps, "warmup": warm, "value": n * steps / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / steps,
+           "perspectives_per_sec": P / dt, "perspectives_per_lattice": P / (steps * n), "stack_buffer_probe": leg.probe, "warm_up": w,
+           "stack_verified": leg.verify(), "roofline": leg.roofline()}
+    out["non_write_us_per_step"] = 1e3 * (out["ms_per_step"] - out["roofline"]["avg_launch_ms"])
+    leg.close()
+    return out
 
 
 def load_trained_weights(d):
@@ -436,6 +534,326 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == world
 
+    ctx = types.SimpleNamespace(args=args, world=world, rank=rank, device=device, red_dev=red_dev, dist_on=dist_on, backend=backend,
+                                result_out=result_out)
+    if max(1, args.shards) > 1 or args.graph or args.policy == "nn11":
+        return run_serial(ctx)
+    return run_explore(ctx)
+
+
+def run_explore(ctx):
+    """The default path: the eps = 1 actor loop through T.ExploreLoop (stack write on the caller's stream, fused step +
+    scan beside it on a second stream), every leg with its own probe report, `roofline` and `stack_verified`."""
+    import torch
+    import torch.distributed as dist
+    import toric_rl_decoder_amd as T
+    from toric_rl_decoder_amd import gather as G
+    from toric_rl_decoder_amd.policy import _forward_chunked
+    args, world, rank, device, red_dev, dist_on, backend, result_out = (ctx.args, ctx.world, ctx.rank, ctx.device, ctx.red_dev, ctx.dist_on,
+                                                                         ctx.backend, ctx.result_out)
+    d, K, W = args.size, args.steps, args.warmup
+    n = args.envs if args.envs is not None else (ENVS_N1 if world == 1 else ENVS_MULTI)
+    nq = 2 * d * d
+    tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "u8": torch.uint8}[args.out_dtype]
+    esize = {"f32": 4, "f16": 2, "bf16": 2, "u8": 1}[args.out_dtype]
+    flush = max(1, args.flush)
+    CH = max(1, args.chunks)
+    if n % CH:
+        sys.exit("--envs must be divisible by --chunks")
+    EV = max(1, min(args.event_every, K))
+    overlap = not args.no_overlap
+    kinds = tuple(k for k in args.stack_kinds.split(",") if k in ("torch", "chunked")) or ("torch",)
+    host_delivery = dist_on and not args.no_transitions and args.delivery in ("auto", "host") and backend == "nccl"
+    roots = args.roots if args.roots > 0 else (2 if world >= 8 else 1)
+    roots = max(1, min(roots, world))
+
+    env = T.make("toric-code-v0", {"size": d, "min_qubit_errors": 0, "p_error": args.p_error})
+    first, _ = G.shard_range(n * world, world, rank)
+    state = {"tg": None}
+
+    def on_flush(blk):                                            # on the loop's side stream, after the priorities
+        if state["tg"] is not None:
+            state["tg"].gather(blk.buf)
+
+    leg = ExploreLeg(T, torch, env, n, d, args.seed, first, tdtype, flush, device, rows=max(K, 8) + 4, chunks=CH, overlap=overlap,
+                     transitions=not args.no_transitions, burn_in=not args.no_burn_in, on_flush=on_flush)
+    have_blocks = leg.blocks is not None
+
+    def make_gather(host):
+        if not (dist_on and have_blocks):
+            return None
+        return G.TransitionGather(leg.blocks[0].nbytes, device, ring_slots=2, host_drain=host, roots=roots)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def warm_collective(g):     # RCCL sets its communicator up lazily: pay for that before anything is timed
+        if g is not None:
+            g.gather(leg.blocks[1].buf)
+            g.wait()
+
+    tg = make_gather(host_delivery)
+    warm_collective(tg)
+    barrier()
+    if not args.no_events:
+        leg.pick_stack(args.stack_candidates, kinds)             # set-up, untimed; every rank probes its own GPU
+    barrier()
+
+    def timed_region():
+        """W untimed + K timed steps, bracketed by barrier + synchronize; -> (seconds, max over ranks; warm-up report)."""
+        w = leg.warm(W, reprobe=not args.no_events)
+        barrier()
+        t0 = time.perf_counter()
+        leg.run(K, EV)
+        if state["tg"] is not None:
+            with torch.cuda.stream(leg.loop.B):
+                state["tg"].wait()
+        barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        if dist_on:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), w
+
+    state["tg"] = tg
+    elapsed, warm_report = timed_region()
+    leg.envs.check()                                              # capacity / action / reset / offsets latch
+    p_all, p_mean = leg.perspectives()
+    p_sum = p_all.sum().reshape(1).to(red_dev)
+    if dist_on:
+        dist.all_reduce(p_sum, op=dist.ReduceOp.SUM)
+    total_steps = float(n) * world * K
+    roof = leg.roofline() if not args.no_events else None
+    verified = leg.verify()
+
+    # ---- every rank's own roofline (N>1): frac, write ms, probe's prediction, gathered to rank 0
+    rank_rows = None
+    if dist_on and roof is not None:
+        mine = torch.tensor([roof["frac"], roof["avg_launch_ms"], roof.get("probe_ms_chosen", float("nan")), roof.get("timed_over_probe", float("nan")),
+                             p_mean, 1.0 if verified["ok"] else 0.0], dtype=torch.float64, device=red_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        num = lambda v: float(v) if float(v) == float(v) else None          # NaN (no probe) -> null
+        rank_rows = [{"rank": r, "frac": float(x[0]), "avg_launch_ms": float(x[1]), "probe_ms_chosen": num(x[2]), "timed_over_probe": num(x[3]),
+                      "perspectives_per_launch": float(x[4]), "stack_verified": bool(x[5] > 0.5)} for r, x in enumerate(allr)]
+
+    # ---- N>1 with host delivery: the same region again with the ring kept in rank 0's HBM
+    hbm_ring = None
+    if host_delivery:
+        state["tg"] = make_gather(False)
+        warm_collective(state["tg"])
+        barrier()
+        el2, _ = timed_region()
+        hbm_ring = {"value": total_steps / el2, "ms_per_step": 1e3 * el2 / K,
+                    "note": "same run, transition ring left in rank 0's HBM (no D2H drain)"}
+    state["tg"] = None
+    leg.envs.releaseParked()
+    time.sleep(0.5)
+
+    n1_legs = world == 1 and not dist_on and args.envs is None and not args.no_shard_leg and CH == 1
+    # ---- N=1 on the default shape: one GPU on the per-GPU shape of the N>1 runs (configs[4]), like for like
+    shard_leg = None
+    if n1_legs:
+        print("[bench] configs[4] shard leg (131072 lattices on this GPU) ...", file=sys.stderr, flush=True)
+        shard_leg = time_explore_leg(T, torch, env, ENVS_MULTI, d, args.seed, tdtype, flush, device, max(8, min(K, 40)), 8,
+                                     candidates=args.stack_candidates, kinds=kinds, event_every=args.event_every, overlap=overlap)
+        shard_leg["envs_per_gpu"] = ENVS_MULTI
+        shard_leg["note"] = ("this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), no collective: "
+                             "the like-for-like base of the scaling curve")
+
+    # ---- N=1: the bf16 stack (TQ_BF16, what the bf16 nn_in_loop variant consumes), same lattices' shape, its own probe and roofline
+    bf16_leg = None
+    if n1_legs and args.bf16_steps > 0 and args.out_dtype == "f32":
+        print("[bench] bf16-stack leg ...", file=sys.stderr, flush=True)
+        bf16_leg = time_explore_leg(T, torch, env, n, d, args.seed, torch.bfloat16, flush, device, args.bf16_steps, 8,
+                                    candidates=args.stack_candidates, kinds=kinds, event_every=args.event_every, overlap=overlap)
+        bf16_leg["note"] = "the same pass with the stack written as bf16 by the kernel itself (numba/util_actor.py:39's cast absorbed)"
+
+    # ---- N=1 on the default shape: BASELINE configs[3] (65 536 lattices, d=9, p=0.15) timed by this very run,
+    # one shot and with the stack written in 4 lattice ranges into a buffer of a quarter of the size (SURVEY 8d C4)
+    c3_leg = None
+    if n1_legs and d == 7 and args.out_dtype == "f32":
+        d3, p3, n3, k3, w3 = 9, 0.15, ENVS_N1, max(8, min(K, 20)), 5
+        env3 = T.make("toric-code-v0", {"size": d3, "min_qubit_errors": 0, "p_error": p3})
+        c3_leg = {"workload": "BASELINE configs[3]: %d lattices, d=%d, p_error=%g, f32 stack; same actor-loop pass" % (n3, d3, p3),
+                  "steps": k3, "warmup": w3}
+        for name, ch in (("one_shot", 1), ("chunks_4", 4)):
+            print("[bench] configs[3] leg (65536 lattices, d=9, p=0.15), %s ..." % name, file=sys.stderr, flush=True)
+            c3_leg[name] = time_explore_leg(T, torch, env3, n3, d3, args.seed, tdtype, flush, device, k3, w3, chunks=ch,
+                                            candidates=args.stack_candidates, kinds=kinds, event_every=args.event_every, overlap=overlap)
+
+    # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured at size in
+    # f32 (what upstream runs) and with the bf16 stack the kernels can write directly + bf16 autocast
+    nn_leg = None
+    if world == 1 and args.nn_steps > 0 and CH == 1:
+        from toric_rl_decoder_amd.policy import NN_11
+        flop_per_persp = 2.0 * sum(ci * co * 9 * ((d - 2) ** 2 if i == 10 else d * d)
+                                   for i, (ci, co) in enumerate(zip((2, 128, 128, 120, 111, 104, 103, 90, 80, 73, 71),
+                                                                    (128, 128, 120, 111, 104, 103, 90, 80, 73, 71, 64))))
+        weights = load_trained_weights(d)
+        nn_leg = {"workload": "configs[2] as written: %d lattices, d=%d: stack -> NN_11 (%s, stock torch conv) -> device "
+                              "eps=%g greedy selection -> fused step" %
+                              (n, d, "the reference's trained d=%d weights" % d if weights is not None else "random init", args.eps),
+                  "steps": args.nn_steps, "variants": {}}
+        envs = leg.envs
+        eps_t = torch.full((n,), args.eps, dtype=torch.float64, device=device)
+        q_buf = torch.empty((leg.cap, 3), dtype=torch.float32, device=device)          # pre-sized: no torch.cat per step
+        p_pin = torch.zeros(1, dtype=torch.int64).pin_memory()
+        p_ready = torch.cuda.Event()
+        off = leg.offs[0][:n + 1]
+        p_nn = []
+
+        def nn_step(model, stack, nn_dtype, t):
+            envs.perspectiveCounts(off)
+            p_pin.copy_(off[n:n + 1], non_blocking=True)          # 8 bytes, behind the scan only
+            p_ready.record()
+            envs.writePerspectives(stack, leg.positions, off)     # enqueued BEFORE the host waits: no bubble behind the read-back
+            p_ready.synchronize()
+            P = int(p_pin.item())
+            p_nn.append(P)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=nn_dtype == "bf16"):
+                # fixed-shape chunks (one MIOpen problem per layer): the last chunk runs into the buffer's slack, its surplus rows are cut off
+                q = _forward_chunked(model, stack[:P], NN_CHUNK, pad_to=NN_CHUNK, backing=stack, out=q_buf)
+            act, _ = envs.selectAction(q, eps_t, positions=leg.positions, offsets=off)
+            blk = leg.blocks[(t // flush) & 1] if have_blocks else None
+            envs.actorStep(act, block=blk, slot=t % flush, want_actions=True)
+            if blk is not None and (t + 1) % flush == 0:
+                blk.computePriorities(n, flush, None, 0.95)       # actor.run_actor passes the Q rows here
+
+        for vname, nn_dtype in (("f32", "f32"), ("bf16", "bf16")):
+            torch.manual_seed(0)
+            m = NN_11(d, 3).to(device).eval()
+            if weights is not None:
+                m.load_state_dict(weights)
+            stack = leg.stack if nn_dtype == "f32" and tdtype == torch.float32 else torch.empty(leg.stack.shape, dtype=torch.bfloat16 if nn_dtype == "bf16" else torch.float32, device=device)
+            print("[bench] nn_in_loop %s: warm-up step (MIOpen picks its kernels) ..." % vname, file=sys.stderr, flush=True)
+            t0 = time.perf_counter()
+            nn_step(m, stack, nn_dtype, 0)
+            torch.cuda.synchronize(device)
+            print("[bench] nn_in_loop %s: warm-up took %.1f s; timing %d step(s) ..." % (vname, time.perf_counter() - t0, args.nn_steps),
+                  file=sys.stderr, flush=True)
+            del p_nn[:]
+            t0 = time.perf_counter()
+            for i in range(args.nn_steps):
+                nn_step(m, stack, nn_dtype, 1 + i)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            P_nn = float(sum(p_nn))
+            nn_leg["variants"][vname] = {"stack_dtype": "bf16" if nn_dtype == "bf16" else args.out_dtype, "nn_dtype": nn_dtype,
+                                         "env_steps_per_sec": n * args.nn_steps / dt, "perspectives_per_sec_into_nn": P_nn / dt,
+                                         "ms_per_step": 1e3 * dt / args.nn_steps, "nn_tflops": P_nn * flop_per_persp / dt / 1e12}
+            del m, stack
+            envs.check()
+        for k_ in ("env_steps_per_sec", "perspectives_per_sec_into_nn", "ms_per_step", "nn_tflops", "nn_dtype"):
+            nn_leg[k_] = nn_leg["variants"]["f32"][k_]                # top level = the f32 run, as upstream
+
+    if rank == 0:
+        cfg_name = config_name(world, n, d, args.p_error)
+        collective = None
+        if dist_on:
+            collective = "transition gather (packed blocks incl. priorities) to %s (%s, %d ranks) every %d steps%s" % (
+                "rank 0" if roots == 1 else "ranks 0..%d in turn" % (roots - 1), backend, dist.get_world_size(), flush,
+                " + D2H drain of every gathered slot to the root's pinned host replay ring" if host_delivery else "; ring in the root's HBM")
+        void = not verified["ok"]
+        res = {
+            "metric": "env steps/sec (batched) at d=%d p=%g" % (d, args.p_error),
+            "value": None if void else total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE %s: %d lattices/GPU, d=%d, p_error=%g; actor-loop pass = "
+                                   "perspective stack (%s) + positions -> selection -> step -> transition "
+                                   "record -> auto-reset (max 75 steps/episode), priorities every %d steps; "
+                                   "policy NN excluded (eps=1 selection in the fused kernel)" %
+                                   (cfg_name, n, d, args.p_error, args.out_dtype, flush),
+                       "policy": args.policy, "envs_per_gpu": n, "d": d, "p_error": args.p_error,
+                       "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
+                       "streams_per_gpu": 2 if overlap else 1, "stack_chunks": CH, "hip_graph": False, "parallelism": "env-shard x%d" % world,
+                       "loop": ("T.ExploreLoop: the stack write on one HIP stream, the fused step + next scan beside it on a second "
+                                "(two plane buffers and two cut-point tables in the handle; two events per step)" if overlap else
+                                "T.ExploreLoop(overlap=False): one stream, the reference's call order"),
+                       "steady_state": not args.no_burn_in, "delivery": ("host" if host_delivery else "hbm") if dist_on else None,
+                       "gather_roots": roots if dist_on else None,
+                       "collective": collective},
+            "perspectives_per_sec": float(p_sum.item()) / elapsed,
+            "perspectives_per_lattice": float(p_sum.item()) / total_steps,
+            "warm_up": warm_report,
+        }
+        if void:
+            res["void"] = "the timed stack buffer holds wrong bytes (stack_verified): no value is reported"
+        if leg.probe is not None:
+            res["stack_buffer_probe"] = leg.probe
+        if hbm_ring is not None:
+            res["hbm_ring"] = hbm_ring
+        res["stack_verified"] = verified
+        if rank_rows is not None:
+            res["ranks"] = rank_rows
+        if shard_leg is not None:
+            res["configs4_shard_on_one_gpu"] = shard_leg
+        if bf16_leg is not None:
+            res["bf16_stack"] = bf16_leg
+        if c3_leg is not None:
+            res["configs3_on_one_gpu"] = c3_leg
+        if roof is not None:
+            alg = roof["bytes_per_step"]
+            traffic, ent = pmc_traffic(d, args.out_dtype, n, args.p_error, CH, p_mean)
+            # context (SURVEY 8d): the box's own streaming-fill bandwidth, measured after the timed region
+            # on the same buffer (hipMemsetAsync through torch), so frac can be read against it as well
+            fb = leg.stack.view(torch.uint8).reshape(-1)[:int(alg) & ~4095]
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fill_ms = []
+            for _ in range(6):
+                f0.record(); fb.zero_(); f1.record(); f1.synchronize()
+                fill_ms.append(f0.elapsed_time(f1))
+            fill_gbps = fb.numel() / (min(fill_ms[1:]) * 1e-3) / 1e9
+            roof.update({"traffic": traffic, "traffic_over_algorithmic": None if traffic is None else traffic / alg,
+                         "traffic_from_profile_run": None if ent is None else True,
+                         "traffic_source": None if ent is None else "%s; counters of the profiled run %s, not of this process" % (
+                             ent.get("source"), ent.get("profiled_at", "profiles/pmc_latest.json")),
+                         "measured_fill_gbps": fill_gbps, "frac_of_measured_fill": roof["achieved"] / fill_gbps})
+            res["roofline"] = roof
+            res["non_write_us_per_step"] = 1e3 * (res["ms_per_step"] - roof["avg_launch_ms"])
+        # every leg's timed write against what its probe promised (VERDICT r03 #1): the legs outside 3 % are named
+        checks = {"headline": roof}
+        if shard_leg is not None:
+            checks["configs4_shard_on_one_gpu"] = shard_leg["roofline"]
+        if bf16_leg is not None:
+            checks["bf16_stack"] = bf16_leg["roofline"]
+        if c3_leg is not None:
+            checks["configs3_on_one_gpu.one_shot"] = c3_leg["one_shot"]["roofline"]
+            checks["configs3_on_one_gpu.chunks_4"] = c3_leg["chunks_4"]["roofline"]
+        res["probe_vs_timed"] = {k_: v["timed_over_probe"] for k_, v in checks.items() if v is not None and "timed_over_probe" in v}
+        res["legs_outside_3pct_of_probe"] = sorted(k_ for k_, v in res["probe_vs_timed"].items() if abs(v - 1.0) > 0.03)
+        bad_legs = [k_ for k_, lg in (("configs4_shard_on_one_gpu", shard_leg), ("bf16_stack", bf16_leg),
+                                       ("configs3.one_shot", c3_leg and c3_leg["one_shot"]), ("configs3.chunks_4", c3_leg and c3_leg["chunks_4"]))
+                    if lg is not None and not lg["stack_verified"]["ok"]]
+        if bad_legs:
+            res["void_legs"] = bad_legs
+        if nn_leg is not None:
+            res["nn_in_loop"] = nn_leg
+        if world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(d, args.p_error, args.seed, args.cpu_seconds)
+        print(json.dumps(res), file=result_out, flush=True)
+        if void:
+            print("[bench] THE TIMED STACK BUFFER HOLDS WRONG BYTES (%d): the numbers of this run are void" % verified["wrong_bytes"], file=sys.stderr, flush=True)
+    leg.close()
+    if dist_on:
+        dist.destroy_process_group()
+    if not verified["ok"]:
+        sys.exit(3)
+
+
+def run_serial(ctx):
+    """The serial loop on one stream in the reference's call order (perspective counts -> stack write -> selection ->
+    step ...): --shards > 1 (independent sub-shards on their own streams), --graph (a flush window captured into a HIP
+    graph) and --policy nn11 (NN_11 in the main loop).  The default path is run_explore."""
+    import torch
+    import torch.distributed as dist
+    import toric_rl_decoder_amd as T
+    from toric_rl_decoder_amd import gather as G
+    args, world, rank, device, red_dev, dist_on, backend, result_out = (ctx.args, ctx.world, ctx.rank, ctx.device, ctx.red_dev, ctx.dist_on,
+                                                                         ctx.backend, ctx.result_out)
     d, K, W = args.size, args.steps, args.warmup
     n = args.envs if args.envs is not None else (ENVS_N1 if world == 1 else ENVS_MULTI)
     nq = 2 * d * d
@@ -575,7 +993,7 @@ def main():
         torch.cuda.empty_cache()
         # rejected candidates stay parked until the timed region is over: the driver wipes freed memory in the background
         sh0.stack, probe = sh0.envs.pickStackBuffer(args.stack_candidates, dtype=tdtype, capacity=cap, positions=sh0.positions, kinds=kinds,
-                                                    park=True, good_enough=args.stack_good_enough)
+                                                    park=True, launches=6)
         probe["note"] = ("set-up, untimed (EnvSet.pickStackBuffer): 3 stack writes timed on each candidate buffer, the fastest kept, "
                          "the others freed; candidate 0 is the allocation a caller gets by default (torch.empty), 'chunked' is "
                          "T.alloc_stack = tq_stack_alloc (2 MiB physical chunks)")
@@ -675,87 +1093,7 @@ def main():
         hbm_ring = {"value": total_steps / el2, "ms_per_step": 1e3 * el2 / K,
                     "note": "same run, transition ring left in rank 0's HBM (no D2H drain)"}
 
-    # ---- N=1 on the default shape: one GPU on the per-GPU shape of the N>1 runs (configs[4]), like for like
-    shard_leg = None
-    if world == 1 and not dist_on and args.envs is None and graph is None and args.policy == "explore" and not args.no_shard_leg:
-        k2, w2 = max(8, min(K, 40)), 8
-        print("[bench] configs[4] shard leg (131072 lattices on this GPU) ...", file=sys.stderr, flush=True)
-        dt2, P2, _ = time_plain_loop(T, torch, env, ENVS_MULTI, d, args.seed, 0, tdtype, flush, device, k2, w2, candidates=args.stack_candidates,
-                                     good_enough=args.stack_good_enough)
-        shard_leg = {"envs_per_gpu": ENVS_MULTI, "steps": k2, "value": ENVS_MULTI * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
-                     "perspectives_per_sec": P2 / dt2, "stack_buffer_probe": time_plain_loop.last_probe,
-                     "stack_verified": time_plain_loop.last_verified,
-                     "note": "this GPU alone on the per-GPU shape of the N>1 runs (BASELINE configs[4]: 131 072 lattices), "
-                             "no collective: the like-for-like base of the scaling curve"}
-
-    # ---- N=1 on the default shape: BASELINE configs[3] (65 536 lattices, d=9, p=0.15) timed by this very run,
-    # one shot and with the stack written in 4 lattice ranges into a buffer of a quarter of the size
-    c3_leg = None
-    if (world == 1 and not dist_on and args.envs is None and d == 7 and graph is None and args.policy == "explore"
-            and not args.no_shard_leg and args.out_dtype == "f32"):
-        d3, p3, n3, k3, w3 = 9, 0.15, ENVS_N1, max(8, min(K, 20)), 5
-        env3 = T.make("toric-code-v0", {"size": d3, "min_qubit_errors": 0, "p_error": p3})
-        c3_leg = {"workload": "BASELINE configs[3]: %d lattices, d=%d, p_error=%g, f32 stack; same actor-loop pass" % (n3, d3, p3),
-                  "steps": k3, "warmup": w3}
-        for name, ch in (("one_shot", 1), ("chunks_4", 4)):
-            print("[bench] configs[3] leg (65536 lattices, d=9, p=0.15), %s ..." % name, file=sys.stderr, flush=True)
-            dt3, P3, ev3 = time_plain_loop(T, torch, env3, n3, d3, args.seed, 0, tdtype, flush, device, k3, w3, chunks=ch, events=True,
-                                           candidates=args.stack_candidates, event_every=args.event_every, good_enough=args.stack_good_enough)
-            alg3 = time_plain_loop.last_p_bracketed * (2 * d3 * d3 * 4 + 12) + n3 * 2 * d3 * d3
-            c3_leg[name] = {"value": n3 * k3 / dt3, "unit": "env-steps/s", "ms_per_step": 1e3 * dt3 / k3,
-                            "stack_buffer_probe": time_plain_loop.last_probe, "stack_verified": time_plain_loop.last_verified,
-                            "perspectives_per_sec": P3 / dt3, "perspectives_per_lattice": P3 / (k3 * n3),
-                            "roofline": {"bound": "hbm", "kernel": STACK_KERNEL, "achieved": alg3 / (ev3.mean() * 1e-3) / 1e9,
-                                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg3 / (ev3.mean() * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                         "bytes_per_step": alg3, "avg_write_ms_per_step": float(ev3.mean()),
-                                         "launches_per_step": ch,
-                                         "note": "HIP events around the stack write(s) of every %d. timed step%s" % (max(1, min(args.event_every, k3)),
-                                                 ("" if ch == 1 else ": the %d range launches and their gaps included (every workgroup finds its own cut points)" % ch))}}
-
-    # ---- N=1: configs[2] as written -- generatePerspective feeding NN_11 for selectAction, measured at size in
-    # f32 (what upstream runs) and with the bf16 stack the kernels can write directly + bf16 autocast
-    nn_leg = None
-    if world == 1 and args.nn_steps > 0 and args.policy == "explore" and graph is None and S == 1 and CH == 1:
-        sh0 = shards[0]
-        flop_per_persp = 2.0 * sum(ci * co * 9 * ((d - 2) ** 2 if i == 10 else d * d)
-                                   for i, (ci, co) in enumerate(zip((2, 128, 128, 120, 111, 104, 103, 90, 80, 73, 71),
-                                                                    (128, 128, 120, 111, 104, 103, 90, 80, 73, 71, 64))))
-        weights = load_trained_weights(d)
-        nn_leg = {"workload": "configs[2] as written: %d lattices, d=%d: stack -> NN_11 (%s, stock torch conv) -> device "
-                              "eps=%g greedy selection -> fused step" %
-                              (n, d, "the reference's trained d=%d weights" % d if weights is not None else "random init", args.eps),
-                  "steps": args.nn_steps, "variants": {}}
-        base = W + K
-        for vname, nn_dtype in (("f32", "f32"), ("bf16", "bf16")):
-            m = make_model()
-            if weights is not None:
-                m.load_state_dict(weights)
-            stack_save = sh0.stack
-            if nn_dtype == "bf16":                                    # the stack written as bf16 by the kernel itself (TQ_BF16)
-                sh0.stack = torch.empty(sh0.stack.shape, dtype=torch.bfloat16, device=device)
-            state["tg"], state["model"], args.nn_dtype = None, m, nn_dtype
-            print("[bench] nn_in_loop %s: warm-up step (MIOpen picks its kernels) ..." % vname, file=sys.stderr, flush=True)
-            t0 = time.perf_counter()
-            one_step(0, base)
-            torch.cuda.synchronize(device)
-            print("[bench] nn_in_loop %s: warm-up took %.1f s; timing %d step(s) ..." % (vname, time.perf_counter() - t0, args.nn_steps),
-                  file=sys.stderr, flush=True)
-            t0 = time.perf_counter()
-            for i in range(args.nn_steps):
-                one_step(0, base + 1 + i)
-            torch.cuda.synchronize(device)
-            dt = time.perf_counter() - t0
-            P_nn = float(sh0.offs[base + 1:base + 1 + args.nn_steps, ns].sum().item())
-            nn_leg["variants"][vname] = {"stack_dtype": "bf16" if nn_dtype == "bf16" else args.out_dtype, "nn_dtype": nn_dtype,
-                                         "env_steps_per_sec": n * args.nn_steps / dt, "perspectives_per_sec_into_nn": P_nn / dt,
-                                         "ms_per_step": 1e3 * dt / args.nn_steps, "nn_tflops": P_nn * flop_per_persp / dt / 1e12}
-            base += 1 + args.nn_steps
-            sh0.stack = stack_save
-            state["model"] = None
-            del m
-            sh0.envs.check()
-        for k_ in ("env_steps_per_sec", "perspectives_per_sec_into_nn", "ms_per_step", "nn_tflops", "nn_dtype"):
-            nn_leg[k_] = nn_leg["variants"]["f32"][k_]                # top level = the f32 run, as upstream
+    shard_leg = c3_leg = nn_leg = None
 
     if rank == 0:
         policy_txt = "policy NN excluded (eps=1 selection in the fused kernel)" if model is None else \
@@ -830,6 +1168,7 @@ def main():
         sh.envs.close()
     if dist_on:
         dist.destroy_process_group()
+
 
 
 if __name__ == "__main__":

@@ -246,13 +246,22 @@ int tq_block_priorities(int d, void* block, int64_t cap, int n_envs, int n_steps
  * tq_select_action).  Outputs (may be NULL): actions_out i32[N,4] (the actions taken),
  * rewards f32[N], terminals u8[N], block/slot: packed transition block with capacity
  * `block_cap` transitions, lattice e writing slot `slot_base + e` (always: an empty slot when it
- * was given a no-op or a rejected action; the priority section is left to tq_block_priorities). */
+ * was given a no-op or a rejected action; the priority section is left to tq_block_priorities).
+ *
+ * Two streams: the step reads the lattices from one buffer of the handle and writes the other (the two take turns),
+ * and tq_persp_count keeps two cut-point tables in turn.  So with actions == NULL (the selection does not look at the
+ * stack) the caller may enqueue tq_actor_step(t) and tq_persp_count(t+1, into a SECOND offsets array) on another stream
+ * than tq_persp_write(t): they run beside the stack write instead of behind it.  The caller orders what the handle
+ * cannot see: tq_persp_write(t) behind tq_persp_count(t); tq_actor_step(t+1) behind tq_persp_write(t) (it overwrites
+ * the buffer that write reads).  On one stream nothing changes.  The set-up and in-place entry points (reset, step,
+ * set_qubits, getters) work on the current buffer in stream order like before. */
 int tq_actor_step(tq_env* h, const int32_t* actions, int32_t* actions_out, float* rewards,
                   uint8_t* terminals, void* block, int64_t block_cap, int64_t slot_base,
                   void* stream);
 
 /* Reads and clears the handle's device error latch (synchronises `stream`): 0, TQ_E_ACTION,
- * TQ_E_CAPACITY, TQ_E_INDEX or TQ_E_RESET. */
+ * TQ_E_CAPACITY, TQ_E_INDEX, TQ_E_RESET or TQ_E_INVALID (offsets handed to tq_persp_write that are not the scan of the
+ * lattices' counts). */
 int tq_check(tq_env* h, void* stream);
 
 #ifdef __cplusplus

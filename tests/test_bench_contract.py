@@ -63,6 +63,7 @@ def test_bench_two_ranks_share_the_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["envs_per_gpu"] == 4096
     assert "2 ranks" in j["config"]["collective"] and j["value"] > 1e6 and j["config"]["gather_roots"] == 2
+    assert [r_["rank"] for r_ in j["ranks"]] == [0, 1] and all(r_["stack_verified"] and r_["frac"] > 0 for r_ in j["ranks"])
     assert abs(j["value"] - 2 * 4096 * 16 / (j["ms_per_step"] * 16e-3)) / j["value"] < 1e-6
 
 
@@ -82,6 +83,9 @@ def test_bench_rccl_path_keeps_stdout_to_one_line():
     j = json.loads(lines[0])
     assert j["config"]["delivery"] == "host" and "nccl, 1 ranks" in j["config"]["collective"]
     assert j["hbm_ring"]["value"] > 1e6 and j["value"] > 1e6
+    rk = j["ranks"]                                           # every rank's own roofline
+    assert len(rk) == 1 and rk[0]["rank"] == 0 and 0 < rk[0]["frac"] < 1 and rk[0]["stack_verified"] is True
+    assert rk[0]["probe_ms_chosen"] > 0 and rk[0]["timed_over_probe"] > 0
 
 
 @pytest.mark.gpu
@@ -107,6 +111,15 @@ def test_bench_json_contract():
     assert set(nn["variants"]) == {"f32", "bf16"} and nn["variants"]["bf16"]["stack_dtype"] == "bf16"
     pr = j["stack_buffer_probe"]                              # set-up probe of the stack buffer's placement, reported in full
     assert pr["kinds"][0] == "torch.empty" and len(pr["write_ms"]) == pr["candidates"] >= 2 and 0 <= pr["chosen"] < pr["candidates"]
+    assert pr["writes_per_candidate"] >= 10 and abs(pr["probe_ms_chosen"] - pr["write_ms"][pr["chosen"]]) < 1e-9 or "reprobe" in pr
+    # every leg explains itself: what the probe promised, what the timed region delivered, what a default allocation would give
+    assert r["probe_ms_chosen"] > 0 and abs(r["timed_write_ms"] - r["avg_launch_ms"]) < 1e-9
+    assert abs(r["timed_over_probe"] - r["timed_write_ms"] / r["probe_ms_chosen"]) < 1e-9
+    assert r["default_buffer"]["kind"] == "torch.empty" and 0 < r["default_buffer"]["frac"] <= 1.0
+    assert set(j["probe_vs_timed"]) == {"headline"} and isinstance(j["legs_outside_3pct_of_probe"], list)
+    assert j["config"]["streams_per_gpu"] == 2 and "ExploreLoop" in j["config"]["loop"]
+    assert j["non_write_us_per_step"] == pytest.approx(1e3 * (j["ms_per_step"] - r["avg_launch_ms"]))
+    assert "warm_write_ms" in j["warm_up"]
     assert j["stack_verified"]["ok"] is True and j["stack_verified"]["wrong_bytes"] == 0      # the timed buffer holds the right bytes
     assert "host_twin" in c and (c["host_twin"].get("value", 0) > 0 or "error" in c["host_twin"])
     assert r["kernel"] == "k_persp_stream" and "custom" in j["config"]["workload"]      # 8192 lattices: not a BASELINE config

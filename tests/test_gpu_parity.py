@@ -883,8 +883,10 @@ def test_hip_equals_the_host_twin_call_for_call(T, d, strategy):
 
 
 def test_reused_stack_buffer_of_the_policy_glue(T):
-    """EnvSet.generatePerspectiveReused: the stack in a buffer the EnvSet keeps (tq_stack_alloc memory), returned
-    as views -- same contents as generatePerspective at every step, same storage from step to step."""
+    """EnvSet.generatePerspectiveReused: the stack in ONE buffer the EnvSet keeps, chosen by a bounded probe at first
+    use (pickStackBuffer, 4 candidates), sized from the observed perspective count with headroom, returned as views --
+    same contents as generatePerspective at every step, same storage from step to step, re-allocated larger when a
+    step outgrows it and when the dtype changes."""
     d, n = 7, 1500
     gpu, ora = make_pair(T, d, n, seed=8, numpy_io=False)
     gpu.resetAll()
@@ -897,9 +899,26 @@ def test_reused_stack_buffer_of_the_policy_glue(T):
         act, qv = gpu.selectAction(None, np.ones(n))               # the positions the glue remembers are the views
         gpu.actorStep(act)
     assert len(ptrs) == 1
-    h8, _, _ = gpu.generatePerspectiveReused(dtype=torch.uint8)
-    f32, _, _ = gpu.generatePerspective()
-    assert torch.equal(h8.float(), f32) and h8.data_ptr() not in ptrs
+    cache = gpu._stack_cache
+    rep = cache["probe"]
+    assert rep["candidates"] == 4 and rep["kinds"][0] == "torch.empty" and rep["writes_per_candidate"] >= 6
+    assert per.shape[0] <= cache["capacity"] < n * 2 * d * d       # observed count x headroom, not the worst case
+    assert gpu.reusedStackBacking().shape[0] == cache["capacity"]
+    # a step that outgrows the buffer: dense syndromes (every qubit a hit)
+    q = np.zeros((n, 2, d, d), np.uint8)
+    q[:, 0, ::2, ::2] = 1
+    q[:, 1, 1::2, 1::2] = 3
+    gpu.setQubits(q)
+    per, pos, cnt = gpu.generatePerspective()
+    assert per.shape[0] > cache["capacity"]
+    rper, rpos, rcnt = gpu.generatePerspectiveReused()
+    assert torch.equal(per, rper) and torch.equal(pos, rpos) and gpu._stack_cache["capacity"] >= per.shape[0]
+    bp, bpos, _, _ = O.generate_perspective_batch(O.syndrome(q))
+    assert np.array_equal(rper.cpu().numpy(), bp.astype(np.float32)) and np.array_equal(rpos.cpu().numpy(), bpos)
+    h8, _, _ = gpu.generatePerspectiveReused(dtype=torch.uint8)    # one cache entry: the f32 buffer is gone
+    assert torch.equal(h8.float(), per) and gpu._stack_cache["dtype"] == torch.uint8
+    big, _, _ = gpu.generatePerspectiveReused(dtype=torch.uint8, capacity=n * 2 * d * d)
+    assert gpu._stack_cache["capacity"] == n * 2 * d * d and torch.equal(big.float(), per)
     gpu.check()
     gpu.close()
 
@@ -1037,3 +1056,54 @@ def test_scan_after_a_large_stack_leaves_no_stale_cut_points(T):
         assert np.array_equal(reused.cpu().numpy(), bp.astype(np.float32)) and np.array_equal(rpos.cpu().numpy(), bpos)
     gpu.check()
     gpu.close()
+
+
+# ------------------------------------------------------------------ the two-stream loop
+@pytest.mark.parametrize("d,n,chunks", [(7, 16384, 1), (5, 8192, 1), (9, 4096, 4)])
+def test_explore_loop_on_two_streams_equals_the_serial_loop_and_the_oracle(T, d, n, chunks):
+    """T.ExploreLoop(overlap=True): the fused step and the next scan run on a second stream BESIDE the stack write (two
+    plane buffers and two cut-point tables in the handle, two events per step).  Free-running for 160 steps -- no host
+    synchronisation inside -- it must leave, step for step, the same stack and positions (integer checksums taken on
+    the write's stream), the same packed transition blocks, and at the end the same lattices and counters as the
+    same loop on ONE stream and as the C oracle's actor loop."""
+    from oracle.c_oracle import CEnvBatch
+    steps, flush, p = 160, 8, P_OF[d]
+    env = T.make("toric-code-v0", {"size": d, "p_error": p})
+    nq = 2 * d * d
+    runs = []
+    for overlap in (True, False):
+        gpu = T.EnvSet(env, n, seed=4321, first_env_id=5, numpy_io=False)
+        gpu.resetAll()
+        cap = (n // chunks) * nq
+        stack = torch.zeros((cap, 2, d, d), dtype=torch.float32, device=gpu.device)
+        pos = torch.zeros((cap, 3), dtype=torch.int32, device=gpu.device)
+        offs = torch.zeros((steps + 2, (n + 2) & ~1), dtype=torch.int64, device=gpu.device)
+        blocks = [gpu.newTransitionBlock(steps=flush) for _ in range(2)]
+        flushed = []
+        loop = T.ExploreLoop(gpu, stack, pos, offs, blocks=blocks, flush=flush, chunks=chunks, overlap=overlap,
+                             on_flush=lambda b: flushed.append(b.buf.clone()))
+        sums = torch.zeros((steps, 2), dtype=torch.int64, device=gpu.device)
+        for t in range(steps):
+            loop.step()
+            sums[t, 0] = stack.view(torch.int32).sum(dtype=torch.int64)      # on the write's stream, behind write(t)
+            sums[t, 1] = pos.sum(dtype=torch.int64)
+        loop.drain()
+        torch.cuda.synchronize()
+        gpu.check()
+        ep, st = gpu.getCounters()
+        runs.append(dict(sums=sums.cpu(), P=offs[:steps, n].cpu(), flushed=[f.cpu() for f in flushed], qubits=gpu.getQubits().cpu().numpy(),
+                         states=gpu.getStates().cpu().numpy(), ep=ep.cpu().numpy(), st=st.cpu().numpy(), stack=stack.cpu(), pos=pos.cpu()))
+        assert loop.overlap == overlap
+        gpu.close()
+    a, b = runs
+    assert torch.equal(a["P"], b["P"]) and torch.equal(a["sums"], b["sums"])
+    assert len(a["flushed"]) == len(b["flushed"]) == steps // flush and all(torch.equal(x, y) for x, y in zip(a["flushed"], b["flushed"]))
+    assert torch.equal(a["stack"], b["stack"]) and torch.equal(a["pos"], b["pos"])
+    for k in ("qubits", "states", "ep", "st"):
+        assert np.array_equal(a[k], b[k]), k
+    ce = CEnvBatch(d, n, p, seed=4321, first_env_id=5)
+    ce.reset()
+    P, _ = ce.actor_steps(steps)
+    assert int(a["P"].sum()) == P
+    assert np.array_equal(a["qubits"], ce.qubits) and np.array_equal(a["states"], ce.states)
+    assert np.array_equal(a["ep"].astype(np.uint32), ce.episodes) and np.array_equal(a["st"].astype(np.uint32), ce.steps)

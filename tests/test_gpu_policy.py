@@ -455,3 +455,38 @@ def test_nn11_on_the_device_stack(T):
     # MIOpen kernel and summation order than q_gpu above -- Q-values to 1e-5 absolute, the greedy choice exact
     assert np.array_equal(a2, o2) and float(np.abs(q2 - oq2.astype(np.float64)).max()) < 1e-5
     gpu.close()
+
+
+def test_forward_chunked_padding_in_the_buffer_slack(T, golden_dir):
+    """policy._forward_chunked: with pad_to=1 it IS the plain forward (bit-identical); with the ragged last chunk run
+    at a padded row count -- surplus rows taken from the slack of the re-used stack buffer, or from a zero-filled copy
+    -- the Q-values agree to 1e-4 absolute (trained weights: Q ~ 90, i.e. ~1e-6 relative; a different batch shape may
+    pick a different convolution kernel) and the greedy choice of every lattice is the same."""
+    import os
+    from safetensors.torch import load_file
+    from toric_rl_decoder_amd.policy import _forward_chunked
+    d, n, chunk = 7, 700, 1 << 14
+    model = T.NN_11(d, 3)
+    model.load_state_dict(load_file(os.path.join(golden_dir, f"nn11_d{d}_converged.safetensors")))
+    model = model.cuda().eval()
+    env = T.make("toric-code-v0", {"size": d, "p_error": 0.1})
+    gpu = T.EnvSet(env, n, seed=23, numpy_io=False)
+    gpu.resetAll()
+    per, pos, cnt = gpu.generatePerspectiveReused()
+    P = per.shape[0]
+    assert P > 2 * chunk and P % 1024 and gpu.reusedStackBacking().shape[0] >= (P + 1023) // 1024 * 1024
+    with torch.no_grad():
+        direct = torch.cat([model(per[i:i + chunk]) for i in range(0, P, chunk)]).float()
+    exact = _forward_chunked(model, per, chunk, pad_to=1)
+    assert torch.equal(exact, direct)                                   # same batch shapes: bit-identical
+    in_slack = _forward_chunked(model, per, chunk, pad_to=1024, backing=gpu.reusedStackBacking())
+    zero_pad = _forward_chunked(model, per.clone(), chunk, pad_to=1024)  # not a view of a larger buffer: zero-filled copy
+    out = torch.empty((P + 7, 3), dtype=torch.float32, device=per.device)
+    into = _forward_chunked(model, per, chunk, pad_to=1024, backing=gpu.reusedStackBacking(), out=out)
+    assert into.data_ptr() == out.data_ptr() and torch.equal(into, in_slack)
+    for q in (in_slack, zero_pad):
+        assert q.shape == (P, 3) and float((q - exact).abs().max()) < 1e-4
+        a = gpu.selectAction(q, 0.0, positions=pos)[0].clone()          # (the method returns its own scratch tensor)
+        b = gpu.selectAction(exact, 0.0, positions=pos)[0].clone()
+        assert torch.equal(a, b) and int((a[:, 3] > 0).sum()) == n      # greedy choice unchanged by the padding
+    gpu.close()

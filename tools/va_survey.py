@@ -17,7 +17,7 @@ for _ in range(30):
 cnt, off = gpu.perspectiveCounts()
 P = int(off[-1].item())
 cap = P + 1000                                             # small candidates: many of them fit
-best, rep = gpu.pickStackBuffer(k, capacity=cap, good_enough=0.0, park=True)
+best, rep = gpu.pickStackBuffer(k, capacity=cap, park=True)
 ms = np.array(rep["write_ms"])
 print("capacity %.2f GB; torch.empty %.1f us at %s" % (cap * 2 * d * d * 4 / 1e9, 1e3 * ms[0], rep["addresses"][0]))
 for a, t in zip(rep["addresses"][1:], ms[1:]):

@@ -13,7 +13,7 @@ from .policy import (NN_11, evaluate, predictMaxOptimized, seed_select, segment_
                      selectActionEnvSet, _selectActionBatch_prime, prediction_smart,
                      generateNPlusQRandomErrors, generateNRandomErrors, generateRandomError)
 
-from .actor import computePrioritiesParallel, run_actor  # noqa: F401,E402
+from .actor import ExploreLoop, computePrioritiesParallel, run_actor  # noqa: F401,E402
 
-__all__ = ["computePrioritiesParallel", "run_actor", "NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "selectActionEnvSet", "seed_select", "prediction_smart", "generateNPlusQRandomErrors", "EnvSet", "ToricEnv", "TransitionBlock", "alloc_stack", "alloc_chunked", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
+__all__ = ["ExploreLoop", "computePrioritiesParallel", "run_actor", "NN_11", "evaluate", "predictMaxOptimized", "segment_max", "selectActionBatch", "selectActionEnvSet", "seed_select", "prediction_smart", "generateNPlusQRandomErrors", "EnvSet", "ToricEnv", "TransitionBlock", "alloc_stack", "alloc_chunked", "generatePerspectiveBatch", "generateTransitionParallel", "make", "to_structured",
            "transition_dtype", "ToricEnvError", "build", "load", "LIB_PATH", "SUPPORTED_SIZES"]

@@ -14,6 +14,107 @@ import torch
 from .policy import selectActionEnvSet
 
 
+class ExploreLoop:
+    """The actor loop body (Actor_mp.py:104-183) at epsilon = 1 -- where upstream starts (Actor_mp.py:37) and where the
+    selection never looks at a Q-value -- with the env kernels BESIDE the stack write instead of behind it:
+
+        stream A (the caller's current stream):  ... write(t) ............................ write(t+1) ...
+        stream B (a side stream):                      step(t) -> [priorities] -> scan(t+1)
+
+    write(t) = tq_persp_write of the pre-step lattices into the caller's stack / positions buffers (what the policy
+    network would read); step(t) = tq_actor_step with in-kernel selection (step, transition record into ``blocks``,
+    auto-reset, counts); scan(t+1) = tq_persp_count into the other of two offsets rows.  The handle keeps two plane
+    buffers and two cut-point tables in turn (include/toricenv.h, tq_actor_step), so the only ordering left to the
+    caller is: write(t) behind scan(t); step(t+1) behind write(t) -- two events per step.  With a Q-table in the loop
+    step(t) depends on the stack and the path is serial (run_actor).  ``overlap=False``: everything on stream A, in
+    the reference's order.
+
+    ``offsets``: (R >= 2, >= no_envs + 1 rounded up to even) int64 tensor; step t scans into row t % R (P of step t stays
+    readable at offsets[t % R, no_envs] until the row is re-used).  ``chunks`` > 1: the stack is written in that many
+    lattice ranges, one after the other, into a buffer of 1/chunks the size (tq_persp_write_range).
+    ``on_flush(block)``: called (on stream B) when a block of ``flush`` steps is complete and its priorities are in
+    -- e.g. gather.TransitionGather.gather."""
+
+    def __init__(self, envs, stack, positions, offsets, blocks=None, flush=8, chunks=1, overlap=True, on_flush=None):
+        assert not envs.numpy_io, "ExploreLoop needs an EnvSet with numpy_io=False"
+        n = envs.no_envs
+        if offsets.dtype != torch.int64 or offsets.dim() != 2 or offsets.shape[0] < 2 or offsets.shape[1] < n + 1 or offsets.shape[1] % 2:
+            raise ValueError("offsets must be an int64 tensor (rows >= 2, even row length >= no_envs + 1)")
+        if n % int(chunks):
+            raise ValueError("no_envs must be divisible by chunks")
+        self.envs, self.stack, self.positions, self.offsets = envs, stack, positions, offsets
+        self.blocks, self.flush, self.chunks, self.on_flush = blocks, int(flush), int(chunks), on_flush
+        self.dev = envs.device
+        self.A = torch.cuda.current_stream(self.dev)
+        self.B = torch.cuda.Stream(device=self.dev) if overlap else self.A
+        self.overlap = self.B is not self.A
+        self.scanned = [torch.cuda.Event() for _ in range(2)]
+        self.written = [torch.cuda.Event() for _ in range(2)]
+        self.t = 0
+        if self.overlap:
+            self.B.wait_stream(self.A)                           # whatever set the lattices up
+        with torch.cuda.stream(self.B):
+            envs.perspectiveCounts(self._row(0))
+            if self.overlap:
+                self.scanned[0].record(self.B)
+
+    def _row(self, t):
+        return self.offsets[t % self.offsets.shape[0]][:self.envs.no_envs + 1]
+
+    def step(self, bracket=None):
+        """One pass.  ``bracket``: a pair of timing events recorded on stream A right before and after the stack write."""
+        envs, t, k = self.envs, self.t, self.t & 1
+        off = self._row(t)
+        if self.overlap:
+            self.A.wait_event(self.scanned[k])
+        if bracket is not None:
+            bracket[0].record(self.A)
+        if self.chunks == 1:
+            envs.writePerspectives(self.stack, self.positions, off)
+        else:
+            per = envs.no_envs // self.chunks
+            for c in range(self.chunks):                          # a consumer would read the buffer between two ranges
+                envs.writePerspectives(self.stack, self.positions, off, first=c * per, count=per)
+        if bracket is not None:
+            bracket[1].record(self.A)
+        if self.overlap:
+            self.written[k].record(self.A)
+        with torch.cuda.stream(self.B):
+            if self.overlap and t > 0:
+                self.B.wait_event(self.written[k ^ 1])            # write(t-1) read the plane buffer this step writes
+            blk = self.blocks[(t // self.flush) % len(self.blocks)] if self.blocks else None
+            envs.actorStep(None, block=blk, slot=t % self.flush, want_actions=True)
+            if blk is not None and (t + 1) % self.flush == 0:
+                blk.computePriorities(envs.no_envs, self.flush, None, 0.95)     # eps = 1: no Q-values, priority = |reward|
+                if self.on_flush is not None:
+                    self.on_flush(blk)
+            envs.perspectiveCounts(self._row(t + 1))
+            if self.overlap:
+                self.scanned[k ^ 1].record(self.B)
+        self.t = t + 1
+
+    def time_writes(self, stack, steps, skip=1):
+        """Run ``skip`` + ``steps`` passes with the stack written into ``stack`` and -> the milliseconds of each of the
+        last ``steps`` stack writes (HIP events on stream A around the write, the env kernels running beside it as in
+        the loop).  Synchronises; for the set-up probe (EnvSet.pickStackBuffer(timer=...))."""
+        keep = self.stack
+        self.stack = stack
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(int(steps))]
+        for _ in range(int(skip)):
+            self.step()
+        for e in evs:
+            self.step(e)
+        self.drain()
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.stack = keep
+        return [a.elapsed_time(b) for a, b in evs]
+
+    def drain(self):
+        """Order stream A behind everything enqueued on stream B so far (no host synchronisation)."""
+        if self.overlap:
+            self.A.wait_stream(self.B)
+
+
 def computePrioritiesParallel(A, R, Q, Qns, discount):
     """Drop-in for util_actor.py:268-287: |R + discount * max_a Qns - Q[a]|.
     A (N,T,4) actions, R (N,T) rewards, Q / Qns (N,T,3) q-values of the state / the next state.

@@ -330,8 +330,12 @@ __device__ __forceinline__ void reset_lattice_wave(typename Lat<D>::State& s, ui
 // ------------------------------------------------------------------ fused actor step
 // Actor_mp.py:116-183 after the policy: step -> transition -> reset(terminal | too many steps)
 // -> perspective counts.  actions == nullptr: pure exploration (eps = 1) drawn in-kernel.
+// The lattices are read from `planes_in` and written to `planes` (the handle's two plane buffers take turns): every
+// plane of every lattice is stored, so the output buffer is complete, and the input buffer stays what the stack
+// write of this step reads.
 template <int D>
-__global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ planes, uint32_t* __restrict__ episodes,
+__global__ __launch_bounds__(256) void k_actor_step(const uint64_t* __restrict__ planes_in, uint64_t* __restrict__ planes,
+                                                    uint32_t* __restrict__ episodes,
                                                     uint32_t* __restrict__ steps, int32_t* __restrict__ counts,
                                                     double* __restrict__ p_roof, const int32_t* __restrict__ actions,
                                                     int32_t* __restrict__ actions_out, float* __restrict__ rewards,
@@ -346,8 +350,8 @@ __global__ __launch_bounds__(256) void k_actor_step(uint64_t* __restrict__ plane
     const bool valid = e_raw < N;
     const int64_t e = valid ? e_raw : N - 1;
     const int lane = threadIdx.x & 63;
-    typename L::State s = load_state<D>(planes, N, e);
-    uint32_t ep = episodes[e], st = steps[e];
+    typename L::State s = load_state<D>(planes_in, N, e);   // read from one buffer, written to the other (below): a stack write
+    uint32_t ep = episodes[e], st = steps[e];               // of the pre-step lattices may run beside this kernel
     const uint32_t env = (uint32_t)(first_env + e);
     int layer, row, col, op;
     bool ok;

@@ -202,7 +202,9 @@ struct tq_env {
     int max_steps;
     int min_err;           // config "min_qubit_errors": 0 = depolarizing sampler, n > 0 = exactly n errors per reset
     tq::PerrSchedule sched;
-    uint64_t* planes;      // [6][W][N]
+    uint64_t* planes;      // [6][W][N]: the lattices
+    uint64_t* planes_alt;  // the second buffer: tq_actor_step reads `planes`, writes this one, then the two swap (so the
+                           // stack write of the pre-step lattices can run beside the step on another stream)
     uint64_t* prev;        // [2][W][N]
     uint32_t* episodes;
     uint32_t* steps;
@@ -216,8 +218,9 @@ struct tq_env {
     void* tblock;          // packed block of N slots: scratch of tq_transition_write
     const uint16_t* lut;
     int num_cus;
-    int32_t* split;        // cut points of the stack write, written by the scan (tq_persp_count)
-    const int64_t* split_for;   // the offsets array they belong to
+    int32_t* split[2];     // cut points of the stack write, written by the scan (tq_persp_count); two tables take turns, so
+    const int64_t* split_for[2];   // the scan of the next step does not overwrite what a running write reads; the offsets
+    int split_last;        // array each belongs to, and which one was written last
 };
 
 namespace {
@@ -407,6 +410,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); };
     alloc((void**)&h->planes, 6 * W * N * 8);
+    alloc((void**)&h->planes_alt, 6 * W * N * 8);
     alloc((void**)&h->prev, 2 * W * N * 8);
     alloc((void**)&h->episodes, N * 4);
     alloc((void**)&h->steps, N * 4);
@@ -416,7 +420,8 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc((void**)&h->err, 4);
     alloc((void**)&h->mark, N * 4);
     alloc(&h->tblock, (size_t)tq::block_bytes(h->w, n_envs));
-    alloc((void**)&h->split, (SPLIT_MAX + 2) * sizeof(int32_t));
+    alloc((void**)&h->split[0], (SPLIT_MAX + 2) * sizeof(int32_t));
+    alloc((void**)&h->split[1], (SPLIT_MAX + 2) * sizeof(int32_t));
     h->reset_epoch = 0;
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
@@ -436,8 +441,8 @@ int tq_destroy(tq_env* h) {
     if (!h) return TQ_OK;
     DeviceGuard guard;
     (void)guard.enter_device(h->device);
-    (void)hipFree(h->mark); (void)hipFree(h->tblock); (void)hipFree(h->split);
-    (void)hipFree(h->planes); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
+    (void)hipFree(h->mark); (void)hipFree(h->tblock); (void)hipFree(h->split[0]); (void)hipFree(h->split[1]);
+    (void)hipFree(h->planes); (void)hipFree(h->planes_alt); (void)hipFree(h->prev); (void)hipFree(h->episodes); (void)hipFree(h->steps);
     (void)hipFree(h->counts); (void)hipFree(h->partial); (void)hipFree(h->p_roof); (void)hipFree(h->err);
     delete h;
     return TQ_OK;
@@ -608,9 +613,11 @@ int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream_) 
     if (!offsets) return fail(TQ_E_INVALID, "offsets is NULL");
     REQUIRE_ALIGNED16(offsets, "offsets");
     REQUIRE_ALIGNED16(counts, "counts");
-    if (int rc = launch_scan(h->counts, h->partial, h->partial_valid, offsets, counts, h->n, stream, h->split)) return rc;
+    const int k = h->split_last ^ 1;                         // not the table the previous scan wrote: a stack write may still read it
+    if (int rc = launch_scan(h->counts, h->partial, h->partial_valid, offsets, counts, h->n, stream, h->split[k])) return rc;
     h->partial_valid = true;
-    h->split_for = offsets;
+    h->split_for[k] = offsets;
+    h->split_last = k;
     return TQ_OK;
 }
 
@@ -625,7 +632,11 @@ int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count
     const uint64_t* vp = h->planes + (size_t)tq::PL_V * h->w * h->n;
     // the cut points of the whole batch came with the scan of these very offsets; for a lattice sub-range, or offsets
     // from elsewhere, the workgroups find theirs themselves
-    const int32_t* split = (first == 0 && count == h->n && offsets == h->split_for) ? h->split : nullptr;
+    const int32_t* split = nullptr;
+    if (first == 0 && count == h->n) {
+        if (offsets == h->split_for[h->split_last]) split = h->split[h->split_last];
+        else if (offsets == h->split_for[h->split_last ^ 1]) split = h->split[h->split_last ^ 1];
+    }
 #define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream, first, count, \
         split)) return rc
     DISPATCH_D(h->d, CALL)
@@ -867,12 +878,13 @@ int tq_actor_step(tq_env* h, const int32_t* actions, int32_t* actions_out, float
         if (slot_base < 0 || slot_base + h->n > block_cap) return fail(TQ_E_CAPACITY, "transition block too small");
         b = tq::block_view(block, h->w, block_cap);
     }
-#define CALL(D) hipLaunchKernelGGL(tq::k_actor_step<D>, grid1(h->n, 256), dim3(256), 0, stream, h->planes, h->episodes, \
+#define CALL(D) hipLaunchKernelGGL(tq::k_actor_step<D>, grid1(h->n, 256), dim3(256), 0, stream, (const uint64_t*)h->planes, h->planes_alt, h->episodes, \
         h->steps, h->counts, h->p_roof, actions, actions_out, rewards, terminals, b, block ? 1 : 0, slot_base, h->sched, \
         (float)h->terminal_reward, h->max_steps, h->min_err, h->seed, h->first_env, (int64_t)h->n, h->err, h->partial)
     DISPATCH_D(h->d, CALL)
 #undef CALL
     KCHECK();
+    { uint64_t* t = h->planes; h->planes = h->planes_alt; h->planes_alt = t; }   // the buffer just written holds the lattices now
     h->partial_valid = true;
     return TQ_OK;
 }

@@ -419,63 +419,81 @@ class EnvSet:
                        _DTYPES[out.dtype])
         self._positions = positions
 
-    def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=3,
-                        kinds=("torch", "chunked"), good_enough=0.83, park=False, first=0, count=None):
+    def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=10,
+                        kinds=("torch", "chunked"), park=False, first=0, count=None, timer=None, passes=2, among=None):
         """Set-up helper: allocate ``candidates`` stack buffers (``capacity`` perspectives each, default the worst
-        case no_envs * 2*d*d), time the stack write of the CURRENT lattices on each of them and keep the fastest.
-        Where a buffer lies in HBM changes the rate of ANY write stream into it by up to 20 % on MI355X (a plain fill
-        included; profiles/r03_stack_write_ab.txt), and a caller writes the same buffer every step, so the choice is
-        worth a few launches at set-up.  ``kinds``: where the candidates come from -- kinds[0] for candidate 0, the
-        rest cyclically for the others: "torch" = torch.empty (candidate 0 by default: what a caller gets without this
-        helper), "chunked" = alloc_stack (2 MiB physical chunks: 6.5-6.7 TB/s against 5.2-5.5 for plain allocations
-        in most runs).  -> (stack tensor (capacity,2,d,d),
-        report dict with the ms and kind of every candidate).  The probe stops early once a candidate takes less than
-        ``good_enough`` x the time of candidate 0 (well-placed buffers take 0.79-0.83 x the time of a plain
-        allocation; on some boxes candidates lie anywhere in between, so a looser threshold stops at a mediocre one).  ``park``: keep the rejected candidates allocated until releaseParked() / close() instead of
-        freeing them here -- the driver wipes freed device memory in the background, tens of GB of it take HBM
-        bandwidth away from whatever runs in the next tens of milliseconds (a benchmark's timed region, say).
-        ``first`` / ``count``: time the write of that lattice range only (a consumer that walks the batch in ranges
+        case no_envs * 2*d*d), time the stack write on each of them and keep the fastest.  On MI355X the rate of a
+        write stream into a buffer depends on the buffer AND on the stream's shape (5.2-6.9 TB/s for this kernel,
+        from allocation to allocation; a buffer that is fast for the f32 stack can be slow for the bf16 stack of the
+        same lattices: profiles/r04_stream_tune_d7_all.txt), and a caller writes the same buffer every step, so the
+        choice is worth a few dozen launches at set-up -- per dtype.
+        ALL candidates are allocated first (and stay allocated while the timing runs), then every candidate is timed
+        ``passes`` times in turn, ``launches`` writes in all, and the MEDIAN decides.  ``timer(stack, k)`` -> list of
+        k write times in ms: what is timed -- default: scan + write of the current lattices, back to back;
+        ExploreLoop.time_writes times the write inside the caller's loop, the env kernels beside it.
+        ``kinds``: where the candidates come from -- kinds[0] for candidate 0, the rest cyclically for the others:
+        "torch" = torch.empty (candidate 0 by default: what a caller has without this helper), "chunked" = alloc_stack
+        (2 MiB physical chunks).  ``among``: time these tensors instead of allocating (a re-probe of parked candidates).
+        -> (stack tensor (capacity,2,d,d), report dict: median / min ms and kind of every candidate, which was kept).
+        ``park``: keep the rejected candidates allocated until releaseParked() / close() instead of freeing them here
+        -- the driver wipes freed device memory in the background, tens of GB of it take HBM bandwidth away from
+        whatever runs in the next tens of milliseconds (a benchmark's timed region, say).
+        ``first`` / ``count``: the default timer writes that lattice range only (a consumer that walks the batch in ranges
         with a small buffer: ``capacity`` is then the small buffer's).  Synchronises; never call it in the step loop."""
         d, nq = self.size, 2 * self.size * self.size
         cap = self.no_envs * nq if capacity is None else int(capacity)
         if positions is None:
             positions = torch.empty((cap, 3), dtype=torch.int32, device=self.device)
-        _, off = self.perspectiveCounts()
-        off = off.clone()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ms, keep, addrs = [], [], []   # every candidate stays allocated until the choice is made: distinct placements
-        used = []
-        for k in range(max(1, int(candidates))):
-            kind = kinds[0] if k == 0 or len(kinds) == 1 else kinds[1 + (k - 1) % (len(kinds) - 1)]
-            c = None
-            if kind == "chunked":
-                try:
-                    c = alloc_stack(cap, d, dtype, self.device)
-                except _lib.ToricEnvError:                    # no virtual-memory API on this driver: plain allocation
-                    kind = "torch"
-            if c is None:
-                c = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
-            used.append("torch.empty" if kind == "torch" else "alloc_stack (2 MiB chunks)")
-            keep.append(c)
-            addrs.append(hex(c.data_ptr()))
-            t = []
-            for r in range(int(launches) + 1):
-                e0.record()
-                self.writePerspectives(c, positions, off, first=first, count=count)
-                e1.record()
-                e1.synchronize()
-                t.append(e0.elapsed_time(e1))
-            ms.append(float(np.mean(t[1:])))
-            if k > 0 and ms[-1] < good_enough * ms[0]:
-                break
+        keep, used = [], []
+        if among is not None:
+            keep = list(among)
+            used = ["re-probed"] * len(keep)
+        else:
+            for k in range(max(1, int(candidates))):
+                kind = kinds[0] if k == 0 or len(kinds) == 1 else kinds[1 + (k - 1) % (len(kinds) - 1)]
+                c = None
+                if kind == "chunked":
+                    try:
+                        c = alloc_stack(cap, d, dtype, self.device)
+                    except _lib.ToricEnvError:                    # no virtual-memory API on this driver: plain allocation
+                        kind = "torch"
+                if c is None:
+                    c = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
+                used.append("torch.empty" if kind == "torch" else "alloc_stack (2 MiB chunks)")
+                keep.append(c)
+                c = None
+        if timer is None:
+            off = self.perspectiveCounts()[1].clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def timer(stack, k):
+                out = []
+                for r in range(k + 1):
+                    e0.record()
+                    self.writePerspectives(stack, positions, off, first=first, count=count)
+                    e1.record()
+                    e1.synchronize()
+                    out.append(e0.elapsed_time(e1))
+                return out[1:]
+        torch.cuda.synchronize(self.device)
+        per_pass = max(1, int(launches) // max(1, int(passes)))
+        samples = [[] for _ in keep]
+        for _ in range(max(1, int(passes))):
+            for i, c in enumerate(keep):
+                samples[i] += list(timer(c, per_pass))
         self.check()
-        best = keep[int(np.argmin(ms))]
+        ms = [float(np.median(x)) for x in samples]
+        chosen = int(np.argmin(ms))
+        best = keep[chosen]
+        rejected = [x for x in keep if x is not best]
         if park:
-            self._parked = getattr(self, "_parked", []) + [x for x in keep if x is not best]
-        del keep, c
+            self._parked = [x for x in getattr(self, "_parked", []) if all(x is not y for y in keep)] + rejected
+        report = {"candidates": len(ms), "write_ms": ms, "write_ms_min": [float(min(x)) for x in samples], "chosen": chosen,
+                  "probe_ms_chosen": ms[chosen], "writes_per_candidate": len(samples[0]), "kinds": used,
+                  "addresses": [hex(x.data_ptr()) for x in keep]}
+        del keep, rejected
         if not park:
             torch.cuda.empty_cache()
-        report = {"candidates": len(ms), "write_ms": ms, "chosen": int(np.argmin(ms)), "kinds": used, "addresses": addrs}
         if len(ms) > 2 and min(ms) > 0.9 * ms[0]:
             report["uniform"] = ("no candidate writes more than 10 % faster than candidate 0: on some boxes every buffer -- and "
                                  "every write stream, hipMemset included -- runs at one rate (profiles/r03_stack_write_ab.txt)")
@@ -486,30 +504,53 @@ class EnvSet:
         self._parked = []
         torch.cuda.empty_cache()
 
-    def generatePerspectiveReused(self, dtype=torch.float32):
-        """generatePerspective for the current states into a stack buffer this EnvSet keeps and re-uses (allocated on
-        first use with alloc_chunked for the worst case, no_envs * 2*d*d perspectives -- 2.5 GB at 65 536 lattices of
-        d=7 in f32 -- without an allocation per step, in the kind of buffer the stack write runs fastest on).  -> (perspectives (P,2,d,d), positions (P,3), counts (N,)) as VIEWS of that buffer: valid until the
-        next call with the same dtype.  For loops that consume the stack at once (the policy's forward pass:
-        numba/util_actor.py:39-46); generatePerspective returns a result of its own like the reference does."""
-        cache = self.__dict__.setdefault("_stack_cache", {})
-        if dtype not in cache:
-            d = self.size
-            cap = self.no_envs * 2 * d * d
-            try:
-                buf = alloc_stack(cap, d, dtype, self.device)
-                pos = alloc_chunked((cap, 3), torch.int32, self.device)
-            except _lib.ToricEnvError:                            # no virtual-memory API on this driver
-                buf = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
-                pos = torch.empty((cap, 3), dtype=torch.int32, device=self.device)
-            cache[dtype] = (buf, pos)
-        buf, pos = cache[dtype]
+    REUSED_PROBE_CANDIDATES = 4     # candidates of the one-off probe behind generatePerspectiveReused (0 / 1 = no probe)
+    REUSED_HEADROOM = 1.5           # capacity of the re-used buffer = observed perspectives x this (grown when exceeded)
+
+    def generatePerspectiveReused(self, dtype=torch.float32, capacity=None):
+        """generatePerspective for the current states into ONE stack buffer this EnvSet keeps and re-uses, for loops that
+        consume the stack at once (the policy's forward pass: numba/util_actor.py:39-46) -- no allocation per step, and
+        the buffer comes from the same probe bench.py uses: at first use (and again when the dtype changes or the
+        buffer has to grow) ``REUSED_PROBE_CANDIDATES`` candidates (one torch.empty, the rest tq_stack_alloc) are timed
+        with the stack write of the current lattices and the fastest is kept (pickStackBuffer; ~0.1-1 s, once).
+        ``capacity`` (perspectives; default: the observed count x REUSED_HEADROOM, at most the worst case
+        no_envs * 2*d*d): 1.0 GB instead of 2.5 GB at 65 536 lattices of d=7 in f32.  When a later step has more
+        perspectives than the buffer holds it is re-allocated larger (the count is read back before the write anyway).
+        -> (perspectives (P,2,d,d), positions (P,3), counts (N,)) as VIEWS of that buffer: valid until the next call."""
+        d, nq = self.size, 2 * self.size * self.size
         counts, offsets = self.perspectiveCounts()
         P = int(offsets[-1].item())
+        worst = self.no_envs * nq
+        cache = self.__dict__.get("_stack_cache")
+        if cache is None or cache["dtype"] != dtype or cache["capacity"] < P or (capacity is not None and cache["capacity"] < min(int(capacity), worst)):
+            want = min(worst, max(int(capacity) if capacity is not None else int(P * self.REUSED_HEADROOM) + 1024, P, 1024))
+            self.__dict__.pop("_stack_cache", None)
+            cache = None
+            torch.cuda.empty_cache()
+            try:
+                pos = alloc_chunked((want, 3), torch.int32, self.device)
+            except _lib.ToricEnvError:                            # no virtual-memory API on this driver
+                pos = torch.empty((want, 3), dtype=torch.int32, device=self.device)
+            k = int(self.REUSED_PROBE_CANDIDATES)
+            if k > 1 and P > 0:
+                buf, report = self.pickStackBuffer(k, dtype=dtype, capacity=want, positions=pos, launches=6, passes=2)
+            else:
+                try:
+                    buf = alloc_stack(want, d, dtype, self.device)
+                except _lib.ToricEnvError:
+                    buf = torch.empty((want, 2, d, d), dtype=dtype, device=self.device)
+                report = None
+            cache = self._stack_cache = {"dtype": dtype, "capacity": want, "buf": buf, "pos": pos, "probe": report}
+        buf, pos = cache["buf"], cache["pos"]
         if P:
             self.writePerspectives(buf, pos, offsets)
         self._positions = pos[:P]
         return buf[:P], pos[:P], counts
+
+    def reusedStackBacking(self):
+        """The whole buffer behind the last generatePerspectiveReused result (rows past P are slack)."""
+        c = self.__dict__.get("_stack_cache")
+        return None if c is None else c["buf"]
 
     def generatePerspective(self, states=None, dtype=torch.float32):
         """generatePerspectiveBatch + concatenate (numba/util_actor.py:33-39,56-67) for the current

@@ -41,25 +41,34 @@ class NN_11(nn.Module):
         return self.linear1(x.flatten(1))
 
 
-def _forward_chunked(model, persp, chunk, pad_to=1024):
-    """model(persp) in chunks of `chunk` rows.  The last, ragged chunk is zero-padded to a multiple of `pad_to` rows
-    (and its Q rows cut off again): the number of perspectives changes every step, and every new batch size is a new
-    problem for MIOpen's solver search -- a handful of shapes instead of thousands."""
-    outs = []
+def _forward_chunked(model, persp, chunk, pad_to=1024, backing=None, out=None):
+    """model(persp) in chunks of `chunk` rows -> (rows, 3) float32.  The number of perspectives changes every step, and
+    every new batch size is a new problem for MIOpen's solver search, so the last, ragged chunk is run at a row count
+    rounded up to a multiple of `pad_to` (its surplus Q rows are cut off again): a handful of shapes instead of
+    thousands.  The surplus rows come from the slack of ``backing`` -- the re-used stack buffer ``persp`` is a view
+    of (EnvSet.reusedStackBacking(): rows past P hold earlier perspectives or zeros) -- when it has enough of it, from a
+    zero-filled copy otherwise.  Batch rows do not influence each other, but a different row count may select a
+    different convolution kernel and summation order: Q-values agree with the unpadded forward to ~1e-6, bit-identity
+    needs ``pad_to=1`` (tests/test_gpu_policy.py pins both, and that the greedy choice is the same on the golden
+    weights).  ``out``: optional (>= rows, 3) float32 tensor to receive the Q-values (no torch.cat)."""
     n = persp.shape[0]
+    if out is None:
+        out = torch.empty((n, 3), dtype=torch.float32, device=persp.device)
     with torch.no_grad():
         for i in range(0, n, chunk):
             x = persp[i:i + chunk]
             r = x.shape[0]
             if r < chunk and pad_to > 1 and r % pad_to:
-                xp = torch.zeros((min(chunk, (r + pad_to - 1) // pad_to * pad_to),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-                xp[:r] = x
-                outs.append(model(xp)[:r].float())
+                rows = min(chunk, (r + pad_to - 1) // pad_to * pad_to)
+                if backing is not None and backing.data_ptr() == persp.data_ptr() and backing.shape[0] >= i + rows:
+                    xp = backing[i:i + rows]
+                else:
+                    xp = torch.zeros((rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                    xp[:r] = x
+                out[i:i + r] = model(xp)[:r]
             else:
-                outs.append(model(x).float())
-    if not outs:
-        return torch.zeros((0, 3), dtype=torch.float32, device=persp.device)
-    return torch.cat(outs, dim=0)
+                out[i:i + r] = model(x)
+    return out[:n]
 
 
 def selectActionEnvSet(envs, model, epsilon, dtype=torch.float32, chunk=1 << 16):
@@ -72,7 +81,7 @@ def selectActionEnvSet(envs, model, epsilon, dtype=torch.float32, chunk=1 << 16)
     envs.numpy_io = False
     try:
         persp, pos, _ = envs.generatePerspectiveReused(dtype=dtype)       # consumed at once by the forward pass
-        q = _forward_chunked(model, persp, chunk)
+        q = _forward_chunked(model, persp, chunk, backing=envs.reusedStackBacking())
         act, qv = envs.selectAction(q, epsilon, positions=pos)
     finally:
         envs.numpy_io = io

@@ -314,10 +314,10 @@ class ExploreLeg:
         """W untimed steps; the last ones' writes are timed and held against the probe: more than 8 % slower -> ONE
         re-probe among the candidates that are still parked, a few more untimed steps."""
         torch = self.torch
-        k = min(max(W, 1), 8)
-        for _ in range(max(0, W - k)):
+        k = min(max(W - 1, 1), 8)              # the first write after the probe (another buffer was written last) is not held against it
+        for _ in range(max(0, W - k - 1)):
             self.loop.step()
-        ms = self.loop.time_writes(self.stack, k, skip=0)
+        ms = self.loop.time_writes(self.stack, k, skip=1 if W > 1 else 0)
         out = {"warm_write_ms": float(np.mean(ms))}
         if self.probe is not None and reprobe:
             p = self.probe["probe_ms_chosen"]
@@ -561,7 +561,8 @@ def run_explore(ctx):
     if n % CH:
         sys.exit("--envs must be divisible by --chunks")
     EV = max(1, min(args.event_every, K))
-    overlap = not args.no_overlap
+    # two streams pay off when a step is long against the host's launch calls: from 16 384 lattices on (profiles/r04_overlap_cost.txt)
+    overlap = not args.no_overlap and n >= 16384
     kinds = tuple(k for k in args.stack_kinds.split(",") if k in ("torch", "chunked")) or ("torch",)
     host_delivery = dist_on and not args.no_transitions and args.delivery in ("auto", "host") and backend == "nccl"
     roots = args.roots if args.roots > 0 else (2 if world >= 8 else 1)
@@ -771,7 +772,7 @@ def run_explore(ctx):
                        "out_dtype": args.out_dtype, "transitions": have_blocks, "flush_steps": flush,
                        "streams_per_gpu": 2 if overlap else 1, "stack_chunks": CH, "hip_graph": False, "parallelism": "env-shard x%d" % world,
                        "loop": ("T.ExploreLoop: the stack write on one HIP stream, the fused step + next scan beside it on a second "
-                                "(two plane buffers and two cut-point tables in the handle; two events per step)" if overlap else
+                                "(two plane buffers and two cut-point tables in the handle; two events per step, the host paces the write behind the scan)" if overlap else
                                 "T.ExploreLoop(overlap=False): one stream, the reference's call order"),
                        "steady_state": not args.no_burn_in, "delivery": ("host" if host_delivery else "hbm") if dist_on else None,
                        "gather_roots": roots if dist_on else None,

@@ -33,9 +33,12 @@ class ExploreLoop:
     readable at offsets[t % R, no_envs] until the row is re-used).  ``chunks`` > 1: the stack is written in that many
     lattice ranges, one after the other, into a buffer of 1/chunks the size (tq_persp_write_range).
     ``on_flush(block)``: called (on stream B) when a block of ``flush`` steps is complete and its priorities are in
-    -- e.g. gather.TransitionGather.gather."""
+    -- e.g. gather.TransitionGather.gather.
+    ``pace``: how write(t) is ordered behind scan(t): "host" (default) -- the host waits for scan(t)'s event before it
+    enqueues write(t), so the host runs at most one step ahead of the GPU and stream A carries no barrier; "device" -- a
+    stream-side wait (hipStreamWaitEvent), the host runs ahead freely, 6-8 us of stream time per step."""
 
-    def __init__(self, envs, stack, positions, offsets, blocks=None, flush=8, chunks=1, overlap=True, on_flush=None):
+    def __init__(self, envs, stack, positions, offsets, blocks=None, flush=8, chunks=1, overlap=True, on_flush=None, pace="host"):
         assert not envs.numpy_io, "ExploreLoop needs an EnvSet with numpy_io=False"
         n = envs.no_envs
         if offsets.dtype != torch.int64 or offsets.dim() != 2 or offsets.shape[0] < 2 or offsets.shape[1] < n + 1 or offsets.shape[1] % 2:
@@ -44,6 +47,9 @@ class ExploreLoop:
             raise ValueError("no_envs must be divisible by chunks")
         self.envs, self.stack, self.positions, self.offsets = envs, stack, positions, offsets
         self.blocks, self.flush, self.chunks, self.on_flush = blocks, int(flush), int(chunks), on_flush
+        if pace not in ("host", "device"):
+            raise ValueError("pace must be 'host' or 'device'")
+        self.pace = pace
         self.dev = envs.device
         self.A = torch.cuda.current_stream(self.dev)
         self.B = torch.cuda.Stream(device=self.dev) if overlap else self.A
@@ -66,7 +72,14 @@ class ExploreLoop:
         envs, t, k = self.envs, self.t, self.t & 1
         off = self._row(t)
         if self.overlap:
-            self.A.wait_event(self.scanned[k])
+            # write(t) behind scan(t).  scan(t) finished long ago -- it ran beside write(t-1) -- but a device-side wait
+            # (a barrier packet in front of the write) still costs stream A 6-8 us per step on MI355X
+            # (profiles/r04_overlap_cost.txt); the HOST waiting for the event costs stream A nothing: write(t-1) is
+            # still running for another ~0.25 ms when the event completes, ample time to enqueue write(t) behind it.
+            if self.pace == "host":
+                self.scanned[k].synchronize()
+            else:
+                self.A.wait_event(self.scanned[k])
         if bracket is not None:
             bracket[0].record(self.A)
         if self.chunks == 1:

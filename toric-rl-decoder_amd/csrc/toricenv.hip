@@ -156,11 +156,14 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
 //     ~3000 cycles of set-up), so d <= 5 gets every wave that is left.
 template <int D, int ES>
 struct StreamCfg {
-    static constexpr int NS = D <= 5 ? 2 : 4;
-    static constexpr int NPW = ES < 4 ? (D >= 13 ? 1 : 2) : 1;
+    static constexpr int NS = D <= 5 ? (D == 5 && ES == 2 ? 3 : 2) : 4;
+    static constexpr int NPW = (ES < 4 && D >= 5 && D < 13) ? 2 : 1;
     static constexpr int NP = D >= 13 ? (ES == 4 ? 3 : 7) : 16 - NS - NPW;
     static constexpr int CPW = 8, RB = 14, RP = 12;          // 8 KiB windows, 64 KB bit ring, 16 KB position ring
 };
+// Tried and not adopted for the producer-bound small lattices: two workgroups per CU (512 workgroups, half-size rings):
+// 39 -> 45 us at d=3, no gain at d=5 -- the producers are bound by the CU's instruction issue, not by latency
+// (profiles/r04_stream_tune_small_two_wgs_per_cu.txt).
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, int* err, hipStream_t stream, int64_t first, int64_t count,

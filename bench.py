@@ -85,7 +85,7 @@ def parse(argv=None):
                          "its own PCIe link (0 = auto: 2 from 8 ranks on, where one Gen5 x16 link no longer carries "
                          "the ~63 GB/s of packed records; 1 below)")
     ap.add_argument("--no-burn-in", action="store_true", help="skip the episode-staggering burn-in")
-    ap.add_argument("--stack-candidates", type=int, default=16,
+    ap.add_argument("--stack-candidates", type=int, default=24,
                     help="stack buffers to allocate at set-up; the one the write kernel is fastest on is kept, the others are "
                          "freed (the write rate depends on the buffer: 5.1-5.5 TB/s into a plain allocation, 6.5-6.8 into most "
                          "tq_stack_alloc buffers on most boxes, profiles/r03_stack_write_ab.txt).  1 = take the first allocation as it comes")

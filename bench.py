@@ -561,8 +561,10 @@ def run_explore(ctx):
     if n % CH:
         sys.exit("--envs must be divisible by --chunks")
     EV = max(1, min(args.event_every, K))
-    # two streams pay off when a step is long against the host's launch calls: from 16 384 lattices on (profiles/r04_overlap_cost.txt)
-    overlap = not args.no_overlap and n >= 16384
+    # two streams pay off when a step is long against the host's launch calls and the ~13 us of env kernels that then run
+    # beside the write: from ~0.25 GB of stack per step on (16 384 lattices of d=7 in f32; 65 536 lattices of d=3 write 64 MB
+    # in 40 us and are faster on one stream: profiles/r04_overlap_cost.txt)
+    overlap = not args.no_overlap and n * 0.75 * nq * nq * esize >= 256e6
     kinds = tuple(k for k in args.stack_kinds.split(",") if k in ("torch", "chunked")) or ("torch",)
     host_delivery = dist_on and not args.no_transitions and args.delivery in ("auto", "host") and backend == "nccl"
     roots = args.roots if args.roots > 0 else (2 if world >= 8 else 1)

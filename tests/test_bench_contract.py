@@ -20,6 +20,20 @@ def test_cpu_baseline_leg_runs_without_gpu():
     assert out["numpy_reference_shaped_steps_per_sec"] > 0
 
 
+def test_roofline_arithmetic_and_config_names():
+    """The `roofline` object of a leg: algorithmic bytes per launch over the mean launch time, against 8 TB/s."""
+    sys.path.insert(0, ROOT)
+    import bench
+    alg = 4790616 * (98 * 4 + 12) + 65536 * 98                # SURVEY 8(d) at configs[2]: P * (2 d^2 * 4 + 12) + N * 2 d^2
+    r = bench.hbm_roofline(alg, [0.29, 0.30, 0.28], {"probe_ms_chosen": 0.29})
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches_timed"] == 3
+    assert abs(r["achieved"] - alg / 0.29e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert r["median_launch_ms"] == 0.29 and r["bytes_per_launch"] == alg and r["probe_ms_chosen"] == 0.29
+    assert bench.config_name(1, 65536, 7, 0.10) == "configs[2]" and bench.config_name(1, 65536, 9, 0.15) == "configs[3]"
+    assert bench.config_name(8, 131072, 7, 0.10) == "configs[4] shape" and bench.config_name(1, 8192, 7, 0.10) == "custom"
+    assert bench.config_name(1, 4096, 5, 0.10) == "configs[1]"
+
+
 def test_self_launcher_starts_the_ranks_and_relays_one_line():
     """`python bench.py --gpus 2` with no torch.distributed.run around it (the driver's command form)
     must start the two ranks itself and print exactly one JSON line with n_gpus == 2.  No GPU here:

@@ -193,10 +193,14 @@ int run(int64_t N, double q, const char* tname) {
         one<D, OutT, 2, 1, 13, 8, 13, 11, 256>(c, false, false);
     } else if (D >= 13) {
         CFG(4, 1, 7, 8, true, true)
+        CFG(4, 1, 5, 8, false, false)
         CFG(4, 1, 4, 8, false, false)
         CFG(4, 1, 3, 8, true, false)
         CFG(4, 1, 2, 8, false, false)
         CFG(4, 2, 3, 8, false, false)
+        CFG(4, 2, 6, 8, ES < 4, false)
+        CFG(4, 2, 10, 8, ES < 4, false)
+        CFG(4, 1, 11, 8, false, false)
         CFG(4, 1, 7, 8, false, false)
     } else {
         CFG(4, 1, 11, 8, true, true)

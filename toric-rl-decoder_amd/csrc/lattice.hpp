@@ -48,9 +48,13 @@ struct Bits {
     TQ_HD int popc() const { int n = 0; for (int k = 0; k < W; ++k) n += popc64(w[k]); return n; }
     TQ_HD int get(int i) const {
         if (W == 1) return (int)((w[0] >> i) & 1);
-        uint64_t word = w[0];
-        for (int k = 1; k < W; ++k) word = ((i >> 6) == k) ? w[k] : word;   // select, no dynamic indexing
-        return (int)((word >> (i & 63)) & 1);
+        // Every word is shifted and masked with "is this the word?" -- NOT a chain of selects between the words: LLVM turns
+        // select(c, w[k], w[0]) into a load through a selected POINTER before the struct is split into registers, which
+        // pins the whole bitset in memory (scratch, or 48-64 bytes of LDS per thread: 37-49 KB per workgroup at d >= 13).
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc |= (w[k] >> (i & 63)) & (uint64_t)((i >> 6) == k);
+        return (int)acc;
     }
     TQ_HD void flip(int i, int on) {
         for (int k = 0; k < W; ++k) w[k] ^= (uint64_t)(on & ((i >> 6) == k)) << (i & 63);

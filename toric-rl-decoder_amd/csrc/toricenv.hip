@@ -147,18 +147,18 @@ int launch_scan(const int32_t* counts, int64_t* partial, bool partial_valid, int
 
 // The stack write (stream_write.hpp): SPLIT_MAX persistent workgroups, one per CU, each with its own contiguous
 // part of the stack.  Waves per workgroup by role, from the sweeps of tools/stream_tune.hip (profiles/r04_stream_tune_*):
-//   * storers: 4 saturate a CU's store path (2 for d <= 5, whose short rows leave the producers more to do);
+//   * storers: 4 saturate a CU's store path (2-3 for d <= 5, whose short rows leave the producers more to do);
 //   * positions waves: 1 for a 4-byte stack; 2 for 16- and 8-bit stacks, which carry 2-4 times the perspectives per
-//     byte stored (u8, d=7: 5.3 -> 6.0-6.2 TB/s);
-//   * producers: whatever the stack needs and NOT more -- idle producers poll and cost the storers issue slots.
-//     d >= 13 (3-4 words per plane, some spilling): 3 producers write a f32 stack faster (6.9 TB/s) than 7 (6.4);
-//     narrow stacks there need the 7.  Small lattices are producer-bound (a d=3 lattice is 1.3 KB of output against
-//     ~3000 cycles of set-up), so d <= 5 gets every wave that is left.
+//     byte stored (u8, d=7: 5.3 -> 6.0-6.2 TB/s; d=9: 6.3 -> 6.5-6.6);
+//   * producers: the rest.  d >= 7 is bound by the store path whatever the mix (d >= 13: 6.9-7.0 TB/s for f32, bf16
+//     and u8 with 2 to 11 producers -- since Bits::get stopped pinning bitsets in scratch / LDS; before that fix 3
+//     producers beat 7 there).  Small lattices are producer-bound (a d=3 lattice is 1.3 KB of output against ~3000
+//     cycles of set-up), so d <= 5 gets every wave that is left.
 template <int D, int ES>
 struct StreamCfg {
     static constexpr int NS = D <= 5 ? (D == 5 && ES == 2 ? 3 : 2) : 4;
-    static constexpr int NPW = (ES < 4 && D >= 5 && D < 13) ? 2 : 1;
-    static constexpr int NP = D >= 13 ? (ES == 4 ? 3 : 7) : 16 - NS - NPW;
+    static constexpr int NPW = (ES < 4 && D >= 5) ? 2 : 1;
+    static constexpr int NP = D >= 13 ? 8 - NPW : 16 - NS - NPW;
     static constexpr int CPW = 8, RB = 14, RP = 12;          // 8 KiB windows, 64 KB bit ring, 16 KB position ring
 };
 // Tried and not adopted for the producer-bound small lattices: two workgroups per CU (512 workgroups, half-size rings):

@@ -449,16 +449,27 @@ class EnvSet:
             keep = list(among)
             used = ["re-probed"] * len(keep)
         else:
-            for k in range(max(1, int(candidates))):
+            # all candidates exist at once: never more of them than half of the free device memory holds
+            nbytes = cap * nq * torch.empty((), dtype=dtype).element_size()
+            with torch.cuda.device(self.device):
+                free = torch.cuda.mem_get_info()[0]
+            wanted = max(1, int(candidates))
+            fit = max(1, min(wanted, int(0.5 * free // max(nbytes, 1))))
+            for k in range(fit):
                 kind = kinds[0] if k == 0 or len(kinds) == 1 else kinds[1 + (k - 1) % (len(kinds) - 1)]
                 c = None
-                if kind == "chunked":
-                    try:
-                        c = alloc_stack(cap, d, dtype, self.device)
-                    except _lib.ToricEnvError:                    # no virtual-memory API on this driver: plain allocation
-                        kind = "torch"
-                if c is None:
-                    c = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
+                try:
+                    if kind == "chunked":
+                        try:
+                            c = alloc_stack(cap, d, dtype, self.device)
+                        except _lib.ToricEnvError:                # no virtual-memory API on this driver (or no memory): plain allocation
+                            kind = "torch"
+                    if c is None:
+                        c = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
+                except torch.OutOfMemoryError:
+                    if not keep:
+                        raise
+                    break                                         # the candidates that exist will do
                 used.append("torch.empty" if kind == "torch" else "alloc_stack (2 MiB chunks)")
                 keep.append(c)
                 c = None
@@ -488,7 +499,7 @@ class EnvSet:
         rejected = [x for x in keep if x is not best]
         if park:
             self._parked = [x for x in getattr(self, "_parked", []) if all(x is not y for y in keep)] + rejected
-        report = {"candidates": len(ms), "write_ms": ms, "write_ms_min": [float(min(x)) for x in samples], "chosen": chosen,
+        report = {"candidates": len(ms), "candidates_asked": int(candidates) if among is None else len(ms), "write_ms": ms, "write_ms_min": [float(min(x)) for x in samples], "chosen": chosen,
                   "probe_ms_chosen": ms[chosen], "writes_per_candidate": len(samples[0]), "kinds": used,
                   "addresses": [hex(x.data_ptr()) for x in keep]}
         del keep, rejected

@@ -54,6 +54,7 @@ STACK_KERNEL = "k_persp_stream"  # the stack-write kernel libtoricenv launches (
 EPISODE = 76                    # a lattice is auto-reset once its step counter exceeds 75 (Distributed_mp.py:44)
 ENVS_N1, ENVS_MULTI = 65536, 131072     # BASELINE configs[2] / configs[4] lattices per GPU
 NN_CHUNK = 16384                # perspectives per NN_11 forward call
+SETTLE = int(os.environ.get("TORIC_BENCH_SETTLE", "64"))   # loop passes at the end of set-up, after the bursty probe (ExploreLeg.pick_stack)
 
 
 def parse(argv=None):
@@ -256,7 +257,8 @@ def hbm_roofline(alg_bytes, write_ms, extra=None):
     ms = float(np.mean(write_ms))
     ach = alg_bytes / (ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": STACK_KERNEL, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-         "bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "median_launch_ms": float(np.median(write_ms)), "launches_timed": int(np.size(write_ms))}
+         "bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "median_launch_ms": float(np.median(write_ms)), "launches_timed": int(np.size(write_ms)),
+         "first_launches_ms": [round(float(x), 4) for x in np.ravel(write_ms)[:(100000 if os.environ.get("TORIC_BENCH_SERIES") == "1" else 8)]]}
     if extra:
         r.update(extra)
     return r
@@ -305,6 +307,15 @@ class ExploreLeg:
         self.stack, self.probe = self.envs.pickStackBuffer(candidates, dtype=self.tdtype, capacity=self.cap, positions=self.positions, kinds=kinds,
                                                            park=True, timer=self.loop.time_writes, launches=10, passes=2)
         self.loop.stack = self.stack
+        # The probe ran in bursts (6 steps, host synchronisation, next candidate).  Set-up ends with SETTLE passes of the loop in
+        # one go: for ~25 steps after such a phase the same write takes 2-3 % longer (a hump that decays by itself,
+        # profiles/r04_first_steps_after_setup.txt) -- it belongs to the change of regime, not to the W warm-up steps or the
+        # timed region that follow.
+        for _ in range(SETTLE):
+            self.loop.step()
+        self.loop.drain()
+        torch.cuda.synchronize(self.device)
+        self.probe["settle_steps"] = SETTLE
         self.probe["note"] = ("set-up, untimed (EnvSet.pickStackBuffer): every candidate allocated first, then the stack write timed INSIDE the "
                               "loop (HIP events around the write, the env kernels beside it) on each candidate in two passes of 5 writes; the "
                               "median decides; candidate 0 is the allocation a caller gets by default (torch.empty), the others T.alloc_stack "
@@ -336,12 +347,23 @@ class ExploreLeg:
         torch.cuda.synchronize(self.device)
         return out
 
-    def run(self, K, every):
-        """K steps; HIP events around every `every`-th stack write.  No synchronisation (the caller brackets)."""
+    def prepare(self, K, every):
+        """Create the timed region's events BEFORE it starts (torch creates the HIP event at the first record: that call
+        belongs to set-up, not between two launches of the timed region)."""
         torch = self.torch
-        self.K, self.every, self.t0 = K, max(1, min(every, K)), self.loop.t
+        self.K, self.every = K, max(1, min(every, K))
         assert self.offs.shape[0] > K + 1, "one offsets row per timed step"
         self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((K + self.every - 1) // self.every)]
+        for a, b in self.ev:
+            a.record(self.loop.A)
+            b.record(self.loop.A)
+        torch.cuda.synchronize(self.device)
+
+    def run(self, K, every):
+        """K steps; HIP events around every `every`-th stack write.  No synchronisation (the caller brackets)."""
+        if self.K != K or self.every != max(1, min(every, K)) or not self.ev:
+            self.prepare(K, every)
+        self.t0 = self.loop.t
         for i in range(K):
             self.loop.step(self.ev[i // self.every] if i % self.every == 0 else None)
         self.loop.drain()
@@ -414,6 +436,7 @@ def time_explore_leg(T, torch, env, n, d, seed, tdtype, flush, device, steps, wa
     leg = ExploreLeg(T, torch, env, n, d, seed, 0, tdtype, flush, device, rows=steps + 4, chunks=chunks, overlap=overlap)
     leg.pick_stack(candidates, kinds)
     w = leg.warm(warm)
+    leg.prepare(steps, event_every)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     leg.run(steps, event_every)
@@ -607,6 +630,7 @@ def run_explore(ctx):
     def timed_region():
         """W untimed + K timed steps, bracketed by barrier + synchronize; -> (seconds, max over ranks; warm-up report)."""
         w = leg.warm(W, reprobe=not args.no_events)
+        leg.prepare(K, EV)
         barrier()
         t0 = time.perf_counter()
         leg.run(K, EV)

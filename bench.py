@@ -343,6 +343,8 @@ class ExploreLeg:
                 self.probe["probe_ms_chosen"] = rep["probe_ms_chosen"]
                 ms = self.loop.time_writes(self.stack, 4, skip=1)
                 out["warm_write_ms_after_reprobe"] = float(np.mean(ms))
+        while self.loop.t % self.flush:         # the timed region starts on a block boundary: every rank flushes (and gathers) at the
+            self.loop.step()                    # same steps of it, however many passes its probe and its re-probe took
         self.loop.drain()
         torch.cuda.synchronize(self.device)
         return out
@@ -629,8 +631,12 @@ def run_explore(ctx):
 
     def timed_region():
         """W untimed + K timed steps, bracketed by barrier + synchronize; -> (seconds, max over ranks; warm-up report)."""
+        # the warm-up (and a rank's own re-probe) takes a rank-dependent number of passes: no collective in it -- every
+        # rank issues exactly the gathers of the K timed steps, K // flush of them, at the same steps
+        gather_, state["tg"] = state["tg"], None
         w = leg.warm(W, reprobe=not args.no_events)
         leg.prepare(K, EV)
+        state["tg"] = gather_
         barrier()
         t0 = time.perf_counter()
         leg.run(K, EV)

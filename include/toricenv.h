@@ -70,7 +70,7 @@ int tq_version(void);
 const char* tq_last_error(void);
 
 /* gym.make('toric-code-v0', config={"size","min_qubit_errors":0,"p_error"}) + EnvSet(env, no_envs)
- * (Distributed_mp.py:72-76, src/EnvSet.py:5-16).  d odd in {3,5,7,9,11,13,15}.  Lattice e of this
+ * (Distributed_mp.py:72-76, src/EnvSet.py:5-16).  d odd in {3,5,...,21}.  Lattice e of this
  * handle has global env id first_env_id + e (shard offset for multi-GPU). */
 int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_t first_env_id);
 int tq_destroy(tq_env* h);

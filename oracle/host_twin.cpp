@@ -285,7 +285,10 @@ void get_state(const tq_env* h, uint8_t* out, bool qubits) {
         case 11: CALL(11); break;    \
         case 13: CALL(13); break;    \
         case 15: CALL(15); break;    \
-        default: return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d); \
+        case 17: CALL(17); break;    \
+        case 19: CALL(19); break;    \
+        case 21: CALL(21); break;    \
+        default: return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d); \
     }
 }  // namespace
 
@@ -299,7 +302,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     *out = nullptr;
     if (device != -1) return fail(TQ_E_INVALID, "this is the host twin of the ABI: device must be -1 (got %d)", device);
     if (n_envs <= 0) return fail(TQ_E_INVALID, "n_envs must be > 0 (got %d)", n_envs);
-    if (d < 3 || d > 15 || !(d & 1)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
+    if (d < 3 || d > 21 || !(d & 1)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d);
     if (first_env_id < 0 || first_env_id + n_envs > 0xFFFFFFFFll) return fail(TQ_E_INVALID, "global env ids must fit in 32 bits");
     tq_env* h = new (std::nothrow) tq_env();
     if (!h) return fail(TQ_E_HIP, "out of host memory");
@@ -400,7 +403,7 @@ int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positi
 }
 
 int64_t tq_transition_block_bytes(int d, int64_t cap) {
-    if (d < 3 || d > 15 || !(d & 1) || cap <= 0) return -1;
+    if (d < 3 || d > 21 || !(d & 1) || cap <= 0) return -1;
     const int W = (d * d + 63) / 64;
     return 4 * 8 * (int64_t)W * cap + 3 * align8(4 * cap) + align8(cap);
 }

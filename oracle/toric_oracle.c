@@ -32,7 +32,7 @@
 #define TOR_DOMAIN_SEL 1u
 #define TOR_DOMAIN_PERR 2u
 #define TOR_MAX_RESET_ROUNDS 4096
-#define TOR_MAX_D 15
+#define TOR_MAX_D 21
 #define TOR_MAX_CELLS (2 * TOR_MAX_D * TOR_MAX_D)
 
 /* ------------------------------------------------------------------ Philox */

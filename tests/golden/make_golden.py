@@ -224,9 +224,9 @@ def numba_variant_vectors(d, states, rp, rpos, rcnt, rng):
 def main():
     rng = np.random.default_rng(20200318)
     report = []
-    for d in (3, 5, 7, 9, 11, 13, 15):        # new sizes last: the draws of the earlier files are unchanged
+    for d in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21):        # new sizes last: the draws of the earlier files are unchanged
         gs = int(d / 2)
-        k = {3: 40, 5: 30, 7: 24, 9: 16, 11: 8, 13: 6, 15: 5}[d]
+        k = {3: 40, 5: 30, 7: 24, 9: 16, 11: 8, 13: 6, 15: 5, 17: 3, 19: 2, 21: 2}[d]
         states = random_states(rng, d, k)
         n = states.shape[0]
 

@@ -127,6 +127,9 @@ static void t_step(int n, uint8_t* q, const int32_t* act, uint8_t* st, int32_t* 
         case 11: CALL(11); break;          \
         case 13: CALL(13); break;          \
         case 15: CALL(15); break;          \
+        case 17: CALL(17); break;          \
+        case 19: CALL(19); break;          \
+        case 21: CALL(21); break;          \
         default: return -1;                \
     }                                      \
     return 0;

@@ -42,7 +42,7 @@ def test_version_and_block_layout(lib):
     assert lib.tq_transition_block_bytes(7, 8) == 4 * 8 * 8 + 32 + 32 + 32 + 8
     assert lib.tq_transition_block_bytes(9, 1000) == 4 * 8 * 2 * 1000 + 3 * 4000 + 1000
     from toric_rl_decoder_amd import wire
-    for d in (3, 5, 7, 9, 11, 13, 15):
+    for d in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21):
         for cap in (1, 7, 64, 1000, 65536):
             assert lib.tq_transition_block_bytes(d, cap) == wire.block_bytes(d, cap)
     assert lib.tq_transition_block_bytes(4, 8) == -1

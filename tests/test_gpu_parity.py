@@ -13,8 +13,8 @@ from oracle import toric_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-SIZES = (3, 5, 7, 9, 11, 13, 15)
-P_OF = {3: 0.1, 5: 0.1, 7: 0.1, 9: 0.15, 11: 0.1, 13: 0.1, 15: 0.08}
+SIZES = (3, 5, 7, 9, 11, 13, 15, 17, 19, 21)
+P_OF = {3: 0.1, 5: 0.1, 7: 0.1, 9: 0.15, 11: 0.1, 13: 0.1, 15: 0.08, 17: 0.08, 19: 0.07, 21: 0.06}
 
 
 @pytest.fixture(scope="module")
@@ -200,6 +200,24 @@ def test_dense_syndrome_maximum_size(T):
     assert np.array_equal(cnt.cpu().numpy(), bcnt)
 
 
+@pytest.mark.parametrize("d,dtype", [(19, torch.float32), (21, torch.uint8), (21, torch.bfloat16), (17, torch.float32)])
+def test_lattice_whose_stack_is_larger_than_the_ring(T, d, dtype):
+    """Every qubit a hit at d >= 19: 2d^2 perspectives of 2d^2 bits are more than the 64 KB bit ring of a workgroup holds
+    (d=21: 778 k bits against 524 k).  The producers publish their progress after every pass of 64 hits and ask for
+    room pass by pass, so such a lattice streams through the ring; mixed with sparse and empty lattices."""
+    rng = np.random.default_rng(d)
+    n = 300
+    st = (rng.random((n, 2, d, d)) < 0.02).astype(np.uint8)
+    st[::7] = 1                                                # dense: all 2 d^2 qubits are hits
+    st[3::11] = 0
+    st[5::13] = (rng.random((len(range(5, n, 13)), 2, d, d)) < 0.6).astype(np.uint8)
+    per, pos, cnt = T.generatePerspectiveBatch(d // 2, d, st, dtype=dtype)
+    bp, bpos, bcnt, _ = O.generate_perspective_batch(st)
+    assert int(cnt[0]) == 2 * d * d                            # (d=21: 882 x 882 = 778 k bits; d=19: 521 k + the storers' lag)
+    assert np.array_equal(cnt.cpu().numpy(), bcnt) and np.array_equal(pos.cpu().numpy(), bpos)
+    assert np.array_equal(per.float().cpu().numpy(), bp.astype(np.float32))
+
+
 @pytest.mark.parametrize("d", SIZES)
 @pytest.mark.parametrize("dtype", (torch.float32, torch.float16, torch.uint8))
 def test_line_ownership_with_empty_and_tiny_lattices(T, d, dtype):
@@ -293,7 +311,7 @@ def test_bad_actions_and_capacity_are_reported(T):
 
 
 # ------------------------------------------------------------------ fused actor step
-@pytest.mark.parametrize("d,strategy", [(3, "random"), (5, "linear"), (7, "fixed"), (9, "random"), (13, "linear"), (15, "random")])
+@pytest.mark.parametrize("d,strategy", [(3, "random"), (5, "linear"), (7, "fixed"), (9, "random"), (13, "linear"), (15, "random"), (17, "fixed"), (21, "random")])
 def test_fused_actor_step_matches_oracle_loop(T, d, strategy):
     """tq_actor_step (step -> transition -> scheduled auto-reset -> counts) against the same loop
     spelled out with oracle calls in the order of Actor_mp.py:104-185."""

@@ -81,7 +81,7 @@ def test_predict_max_optimized(T, d):
     assert np.array_equal(plain, ref)
 
 
-@pytest.mark.parametrize("d", (3, 5, 7, 9, 11, 13, 15))
+@pytest.mark.parametrize("d", (3, 5, 7, 9, 11, 13, 15, 17, 19, 21))
 def test_learner_goldens_from_the_reference(T, golden_dir, d):
     """predictMaxOptimized and computePrioritiesParallel against vectors produced by running the
     reference's own functions (tests/golden/make_golden.py): the device path, the numpy drop-in and

@@ -15,8 +15,8 @@ from oracle import host_twin as H
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "toric-rl-decoder_amd"))
 import wire  # noqa: E402  (pure numpy: the product's wire format module)
 
-SIZES = (3, 5, 7, 9, 11, 13, 15)
-P_OF = {3: 0.1, 5: 0.1, 7: 0.1, 9: 0.15, 11: 0.1, 13: 0.1, 15: 0.08}
+SIZES = (3, 5, 7, 9, 11, 13, 15, 17, 19, 21)
+P_OF = {3: 0.1, 5: 0.1, 7: 0.1, 9: 0.15, 11: 0.1, 13: 0.1, 15: 0.08, 17: 0.08, 19: 0.07, 21: 0.06}
 
 
 def test_twin_is_for_device_minus_one_only():

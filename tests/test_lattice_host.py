@@ -12,7 +12,7 @@ import pytest
 from oracle import toric_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIZES = (3, 5, 7, 9, 11, 13, 15)
+SIZES = (3, 5, 7, 9, 11, 13, 15, 17, 19, 21)
 
 
 @pytest.fixture(scope="module")
@@ -109,7 +109,7 @@ def test_fixed_n_sampler_matches_oracle(shim, d):
         assert np.array_equal(q, oq) and np.array_equal(st, os_)
         assert ((q != 0).reshape(n, -1).sum(1) == n_err).all() and st.reshape(n, -1).any(1).all()
     # uniformity over positions (one error, many lattices): every qubit is hit about equally often
-    big = 20000
+    big = max(20000, 120 * 2 * d * d)                       # ~120 expected hits per qubit at least
     q1, _ = O.reset_lattices(1, np.arange(big), 0, 0.1, d, min_errors=1)
     hits = (q1 != 0).reshape(big, -1).sum(0)
     assert hits.sum() == big and hits.min() > 0.6 * big / (2 * d * d)

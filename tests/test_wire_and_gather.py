@@ -33,7 +33,7 @@ def make_priorities(n, seed):
     return p
 
 
-@pytest.mark.parametrize("d", (3, 5, 7, 9, 11, 13, 15))
+@pytest.mark.parametrize("d", (3, 5, 7, 9, 11, 13, 15, 17, 19, 21))
 def test_wire_round_trip(d):
     n, cap = 37, 64
     per, nper, act, rew, term = make_transitions(d, n, 3)
@@ -54,7 +54,7 @@ def test_wire_round_trip(d):
     assert wire.decode(buf, d, cap, drop_empty=False)["perspective"].shape[0] == cap
     rec, pr = wire.to_records(out, d)                        # the (transition, priority) pairs of IO_mp.py:60-66
     assert rec.dtype == wire.transition_type(d)
-    assert rec.dtype.itemsize == {3: 329, 5: 841, 7: 1609, 9: 2633, 11: 3913, 13: 5449, 15: 7241}[d]
+    assert rec.dtype.itemsize == {3: 329, 5: 841, 7: 1609, 9: 2633, 11: 3913, 13: 5449, 15: 7241, 17: 9289, 19: 11593, 21: 14153}[d]
     assert np.array_equal(rec["action"]["position"][:, 1], np.full(n, d // 2))
     assert pr.dtype == np.float32 and np.array_equal(pr, prio) and len(list(zip(rec, pr))) == n
     assert wire.block_bytes(7, 1 << 16) == (1 << 16) * 45                          # 45 B / transition at d=7

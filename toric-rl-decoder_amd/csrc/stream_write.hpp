@@ -147,7 +147,9 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
     constexpr int LPD = 32 / VEC;                            // lanes that share one ring dword
     constexpr uint32_t RING_BITS = 32u << RB_LOG, BMASK = (1u << RB_LOG) - 1u;
     constexpr uint32_t RP = 1u << RP_LOG, PMASK = RP - 1u;
-    static_assert((uint32_t)NQ * NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS, "bit ring too small for this lattice size");
+    // a producer asks for ring room one pass of 64 hits at a time and publishes its progress after every pass, so the ring
+    // has to hold one pass plus what the storers may lag behind -- not a whole lattice (2d^2 hits of 2d^2 bits each)
+    static_assert(64u * (uint32_t)NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS, "bit ring too small for this lattice size");
     static_assert((uint32_t)NQ + 512u < RP, "position ring too small");
     __shared__ StreamLds<D, NS, NP, RB_LOG, RP_LOG, NPW> S;
 
@@ -386,6 +388,39 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
     }
     const int64_t QT = Q1 + need_extra;                      // lattices are produced while they start in front of QT
     uint32_t lw_c = a0, pc_c = 0u;                           // cached low-water marks of the storers
+    // wait until the rings have room for the stream bits below `bits_end` and the positions below `q_end`; wave-uniform;
+    // false = the workgroup gave up (the caller returns)
+    auto wait_room = [&](uint32_t bits_end, uint32_t q_end) -> bool {
+        auto fits = [&]() {
+            return (lw_c == 0xFFFFFFFFu || bits_end + 64u <= lw_c + RING_BITS) && (!has_pos || pc_c == 0xFFFFFFFFu || q_end <= pc_c + RP);
+        };
+        if (fits()) return true;
+        unsigned long long t0 = 0;
+        if (STATS) t0 = __builtin_readcyclecounter();
+        for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
+            uint32_t c = 0xFFFFFFFFu;
+            if (has_stack && lane < NS) c = __hip_atomic_load(&S.cons[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int o = 1; o < NS; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)c, o, 64); c = t < c ? t : c; }
+            lw_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (has_pos) {
+                uint32_t pc = 0xFFFFFFFFu;
+                if (lane < NPW) pc = __hip_atomic_load(&S.pcons[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int o = 1; o < NPW; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)pc, o, 64); pc = t < pc ? t : pc; }
+                pc_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc);
+            }
+            if (fits()) {
+                lds_after_peek();
+                if (STATS) t_a += __builtin_readcyclecounter() - t0;
+                return true;
+            }
+            if (lds_peek(S.abort)) return false;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        give_up();
+        return false;
+    };
     for (int64_t Lb = 0;; Lb += 64 * NP) {
         // the planes and offsets of this wave's next 64 lattices in one round of vector loads
         const int64_t e_l = e_lo + Lb + (int64_t)lane * NP + p;
@@ -413,37 +448,15 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
             if (readlane64((uint64_t)oo1, j) - readlane64((uint64_t)oo, j) != (uint64_t)n) { give_up(); return; }
             if (n == 0) continue;
             const uint32_t q0 = (uint32_t)((int64_t)readlane64((uint64_t)oo, j) - Q0);
-            const uint32_t bit0 = head + q0 * (uint32_t)NQ, bit1 = bit0 + (uint32_t)n * NQ;
+            const uint32_t bit0 = head + q0 * (uint32_t)NQ;
             // this wave's earlier lattices are in the rings (its LDS operations execute in issue order): say so
             lds_publish(S.pq[p], q0, lane);
             // ---- room in the rings: everything below the storers' low-water mark has been handed back.  The marks
             // are cached: while the storers keep up the ring is nearly empty and one look lasts for dozens of lattices.
+            // Positions: the whole lattice (n <= 2d^2 < ring - 512); bits: the first pass of 64 hits (later passes below).
             if (STATS) ++n_items;
-            if (!((lw_c == 0xFFFFFFFFu || bit1 + 64u <= lw_c + RING_BITS) && (!has_pos || pc_c == 0xFFFFFFFFu || q0 + (uint32_t)n <= pc_c + RP))) {
-                bool ok = false;
-                unsigned long long t0 = 0;
-                if (STATS) t0 = __builtin_readcyclecounter();
-                for (int spin = 0; spin < STREAM_SPIN_LIMIT; ++spin) {
-                    uint32_t c = 0xFFFFFFFFu;
-                    if (has_stack && lane < NS) c = __hip_atomic_load(&S.cons[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                    for (int o = 1; o < NS; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)c, o, 64); c = t < c ? t : c; }
-                    lw_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                    if (has_pos) {
-                        uint32_t pc = 0xFFFFFFFFu;
-                        if (lane < NPW) pc = __hip_atomic_load(&S.pcons[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                        for (int o = 1; o < NPW; o <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)pc, o, 64); pc = t < pc ? t : pc; }
-                        pc_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)pc);
-                    }
-                    if ((lw_c == 0xFFFFFFFFu || bit1 + 64u <= lw_c + RING_BITS) && (!has_pos || pc_c == 0xFFFFFFFFu || q0 + (uint32_t)n <= pc_c + RP)) { ok = true; break; }
-                    if (lds_peek(S.abort)) return;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                if (!ok) { give_up(); return; }
-                lds_after_peek();
-                if (STATS) t_a += __builtin_readcyclecounter() - t0;
-            }
+            const uint32_t pass1 = (uint32_t)(n < 64 ? n : 64);
+            if (!wait_room(bit0 + pass1 * (uint32_t)NQ, q0 + (uint32_t)n)) return;
             // ---- tables: rotated planes (ballot), row-rolled planes, hit list
             B rv, rp;
 #pragma unroll
@@ -454,8 +467,8 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                 rv.w[k] = __ballot(inb && v.get(PS::rot_src_v(oc)));
                 rp.w[k] = __ballot(inb && pl.get(PS::rot_src_p(oc)));
             }
-            if (lane < 4 * D) {
-                const int sel = lane / D, k = lane - sel * D;
+            for (int t = lane; t < 4 * D; t += 64) {         // one lane per (plane, row amount): 4 d entries (more than 64 from d = 17 on)
+                const int sel = t / D, k = t - sel * D;
                 B src;
 #pragma unroll
                 for (int w = 0; w < W; ++w) src.w[w] = sel == 0 ? v.w[w] : (sel == 1 ? pl.w[w] : (sel == 2 ? rv.w[w] : rp.w[w]));
@@ -474,8 +487,17 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                 }
             }
             wave_lds_sync();
-            // ---- one lane per hit: its perspective as two bit-planes, OR-ed into the ring
-            for (int k = lane; k < n; k += 64) {
+            // ---- one lane per hit, 64 hits per pass: its perspective as two bit-planes, OR-ed into the ring.  After every pass
+            // the wave says how far the lattice is (the consumers may take it) and asks for the next pass's room: a lattice
+            // never has to fit into the ring as a whole (d >= 19: 2d^2 hits x 2d^2 bits are more than the ring holds)
+            for (int kb = 0; kb < n; kb += 64) {
+                if (kb) {
+                    lds_publish(S.pq[p], q0 + (uint32_t)kb, lane);
+                    const uint32_t upto = (uint32_t)(n < kb + 64 ? n : kb + 64);
+                    if (!wait_room(bit0 + upto * (uint32_t)NQ, q0 + (uint32_t)n)) return;
+                }
+                const int k = kb + lane;
+                if (k >= n) continue;
                 const uint32_t hp = T.hpos[k];
                 const int layer = (int)(hp & 255u), i = (int)((hp >> 8) & 255u), jj = (int)(hp >> 16);
                 int rs, cs;

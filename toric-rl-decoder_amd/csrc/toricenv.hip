@@ -42,7 +42,7 @@ int fail(int code, const char* fmt, ...) {
 #define KCHECK() HIPCHECK(hipGetLastError())
 
 constexpr int MAX_DEVICES = 16;
-constexpr int kSizes[] = {3, 5, 7, 9, 11, 13, 15};
+constexpr int kSizes[] = {3, 5, 7, 9, 11, 13, 15, 17, 19, 21};
 
 bool size_ok(int d) {
     for (int s : kSizes) if (s == d) return true;
@@ -53,7 +53,7 @@ int size_slot(int d) { return (d - 3) / 2; }
 // per-device caches shared by handles and the stateless entry points
 struct DeviceCtx {
     std::mutex mu;
-    uint16_t* lut[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint16_t* lut[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int* err = nullptr;             // error latch of the stateless entry points (tq_states_check)
     void* ws = nullptr;             // scratch of the tq_states_persp_* entry points (tq_states_reserve)
     size_t ws_bytes = 0;
@@ -94,7 +94,10 @@ int decode_latch(int flag) {
         case 11: CALL(11); break;    \
         case 13: CALL(13); break;    \
         case 15: CALL(15); break;    \
-        default: return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d); \
+        case 17: CALL(17); break;    \
+        case 19: CALL(19); break;    \
+        case 21: CALL(21); break;    \
+        default: return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d); \
     }
 
 int current_device(int* dev) {
@@ -158,7 +161,7 @@ template <int D, int ES>
 struct StreamCfg {
     static constexpr int NS = D <= 5 ? (D == 5 && ES == 2 ? 3 : 2) : 4;
     static constexpr int NPW = (ES < 4 && D >= 5) ? 2 : 1;
-    static constexpr int NP = D >= 13 ? 8 - NPW : 16 - NS - NPW;
+    static constexpr int NP = D >= 17 ? 3 : (D >= 13 ? 8 - NPW : 16 - NS - NPW);   // d >= 17: 5-7 words per plane, 8 waves = 256 VGPRs each
     static constexpr int CPW = 8, RB = 14, RP = 12;          // 8 KiB windows, 64 KB bit ring, 16 KB position ring
 };
 // Tried and not adopted for the producer-bound small lattices: two workgroups per CU (512 workgroups, half-size rings):
@@ -393,7 +396,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     if (!out) return fail(TQ_E_INVALID, "out is NULL");
     *out = nullptr;
     if (n_envs <= 0) return fail(TQ_E_INVALID, "n_envs must be > 0 (got %d)", n_envs);
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d);
     if (first_env_id < 0 || first_env_id + n_envs > 0xFFFFFFFFll)
         return fail(TQ_E_INVALID, "global env ids must fit in 32 bits");
     int ndev = 0;
@@ -663,7 +666,7 @@ static size_t states_scratch_bytes(int d, int64_t n) {
 
 // set-up call: allocates (and synchronises); the tq_states_persp_* calls themselves never allocate
 int tq_states_reserve(int d, int n_max) {
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d);
     if (n_max <= 0) return fail(TQ_E_INVALID, "n_max must be > 0");
     int dev;
     if (int rc = current_device(&dev)) return rc;
@@ -699,7 +702,7 @@ static int states_scratch(int dev, int d, int n, uint64_t** vp, int32_t** counts
 
 int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, int64_t* offsets, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d);
     if (n <= 0 || !states || !offsets) return fail(TQ_E_INVALID, "bad n / states / offsets");
     REQUIRE_ALIGNED16(offsets, "offsets");
     REQUIRE_ALIGNED16(counts, "counts");
@@ -722,7 +725,7 @@ int tq_states_persp_count(int d, int n, const uint8_t* states, int32_t* counts, 
 int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* offsets, void* out,
                           int32_t* positions, int64_t capacity, int dtype, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d);
     if (n <= 0 || !states || !offsets || !out || capacity < 0) return fail(TQ_E_INVALID, "bad arguments");
     REQUIRE_ALIGNED16(out, "out");
     REQUIRE_ALIGNED16(positions, "positions");
@@ -745,7 +748,7 @@ int tq_states_persp_write(int d, int n, const uint8_t* states, const int64_t* of
 int tq_states_transition(int d, int n, const uint8_t* states, const uint8_t* next_states, const int32_t* actions,
                          uint8_t* persp, uint8_t* next_persp, int32_t* actions_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d);
     if (n <= 0 || !actions || (persp && !states) || (next_persp && !next_states)) return fail(TQ_E_INVALID, "bad arguments");
     REQUIRE_ALIGNED16(actions, "actions");
     REQUIRE_ALIGNED16(actions_out, "actions_out");
@@ -841,7 +844,7 @@ int tq_transition_write(tq_env* h, const int32_t* actions, uint8_t* persp, uint8
 int tq_block_priorities(int d, void* block, int64_t cap, int n_envs, int n_steps, const float* q_values,
                         double discount, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d);
     if (!block || n_envs <= 0 || n_steps <= 0 || (int64_t)n_envs * n_steps > cap)
         return fail(TQ_E_INVALID, "bad block / n_envs / n_steps (n_envs * n_steps must be <= cap)");
     tq::BlockView b = tq::block_view(block, (d * d + 63) / 64, cap);
@@ -855,7 +858,7 @@ int tq_transition_unpack(int d, const void* block, int64_t cap, int64_t first, i
                          uint8_t* next_persp, int32_t* actions, float* rewards, uint8_t* terminals, float* priorities,
                          void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..15)", d);
+    if (!size_ok(d)) return fail(TQ_E_INVALID, "unsupported lattice size d=%d (odd 3..21)", d);
     if (!block || first < 0 || count < 0 || first + count > cap) return fail(TQ_E_INVALID, "bad block / slot range");
     if (count == 0) return TQ_OK;
     REQUIRE_ALIGNED16(actions, "actions");

@@ -25,7 +25,7 @@ from ._lib import TQ_BF16, TQ_F16, TQ_F32, TQ_U8, check
 
 _DTYPES = {torch.float32: TQ_F32, torch.float16: TQ_F16, torch.bfloat16: TQ_BF16, torch.uint8: TQ_U8}
 _STRATEGY = {None: 0, "fixed": 0, "linear": 1, "random": 2}
-SUPPORTED_SIZES = (3, 5, 7, 9, 11, 13, 15)
+SUPPORTED_SIZES = (3, 5, 7, 9, 11, 13, 15, 17, 19, 21)
 
 
 def _stream():

@@ -69,16 +69,17 @@ def test_bench_two_ranks_share_the_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "8",
-                        "--envs", "4096", "--cpu-seconds", "0", "--roots", "2"], capture_output=True, text=True, timeout=900,
+                        "--envs", "32768", "--cpu-seconds", "0", "--nn-steps", "0", "--roots", "2"], capture_output=True, text=True, timeout=900,
                        env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["envs_per_gpu"] == 4096
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["envs_per_gpu"] == 32768
+    assert j["config"]["streams_per_gpu"] == 2        # the two-stream loop: the gathers are issued from its side stream
     assert "2 ranks" in j["config"]["collective"] and j["value"] > 1e6 and j["config"]["gather_roots"] == 2
     assert [r_["rank"] for r_ in j["ranks"]] == [0, 1] and all(r_["stack_verified"] and r_["frac"] > 0 for r_ in j["ranks"])
-    assert abs(j["value"] - 2 * 4096 * 16 / (j["ms_per_step"] * 16e-3)) / j["value"] < 1e-6
+    assert abs(j["value"] - 2 * 32768 * 16 / (j["ms_per_step"] * 16e-3)) / j["value"] < 1e-6
 
 
 @pytest.mark.gpu
@@ -89,13 +90,13 @@ def test_bench_rccl_path_keeps_stdout_to_one_line():
     env = dict(os.environ, TORIC_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):   # no port given: bench.py picks a free one
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--envs", "8192",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--envs", "32768",
                         "--cpu-seconds", "0", "--nn-steps", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[:500]
     j = json.loads(lines[0])
-    assert j["config"]["delivery"] == "host" and "nccl, 1 ranks" in j["config"]["collective"]
+    assert j["config"]["delivery"] == "host" and "nccl, 1 ranks" in j["config"]["collective"] and j["config"]["streams_per_gpu"] == 2
     assert j["hbm_ring"]["value"] > 1e6 and j["value"] > 1e6
     rk = j["ranks"]                                           # every rank's own roofline
     assert len(rk) == 1 and rk[0]["rank"] == 0 and 0 < rk[0]["frac"] < 1 and rk[0]["stack_verified"] is True

@@ -1,34 +1,43 @@
 #!/usr/bin/env python3
 """Headline benchmark of the toric-code env hot path on MI355X.
 
-A "step" is one pass of the hot path over one batch of lattices, in the call order of the
-reference's actor loop (src/Actor_mp.py:104-185) with the policy network left out of the headline
-(it is stock torch conv work, out of scope; epsilon starts at 1 upstream, Actor_mp.py:37, where the
-Q-values never influence the action):
+A "step" is one pass of the hot path over one batch of lattices, the body of the reference's actor loop
+(src/Actor_mp.py:104-185) with the policy network left out of the headline (it is stock torch conv work, out of scope;
+epsilon starts at 1 upstream, Actor_mp.py:37, where the Q-values never influence the action):
 
-    perspective counts -> exclusive scan -> perspective stack write (P,2,d,d) f32 + positions
-    -> eps=1 selection, env step, transition record, auto-reset, next counts (one fused kernel)
-    -> every --flush steps: priorities into the packed block (computePrioritiesParallel with Q = 0)
+    perspective stack write (P,2,d,d) f32 + positions            (stream A)
+    eps=1 selection, env step, transition record, auto-reset, next counts (one fused kernel) -> exclusive scan of the
+    counts -> every --flush steps: priorities into the packed block (computePrioritiesParallel with Q = 0)   (stream B)
 
-Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on: 65 536
-lattices, d=7, p_error=0.10.  Lattices are resident in HBM when the timed region starts; nothing
-crosses PCIe in the N=1 loop.  Before the warm-up the episodes are staggered (burn-in: lattice e is
-reset at step e mod 76), so the population -- and with it perspectives per lattice -- is stationary
-and `value` does not depend on --steps.
+through toric_rl_decoder_amd.ExploreLoop: the fused step does not depend on the stack at eps = 1, so it and the next scan
+run on a second HIP stream BESIDE the stack write (--no-overlap = one stream, the reference's call order;
+small batches run on one stream anyway).
 
-N>1: `python bench.py --gpus N` starts N ranks by itself (a `python -m torch.distributed.run` child,
-before this process touches the GPU) and relays rank 0's JSON line; under torch.distributed.run
-(WORLD_SIZE set) it runs as a rank.  One rank per GPU; every rank owns a contiguous block of global
-env ids (weak scaling).  Default shape for N>1: BASELINE.json configs[4] -- 131 072 lattices per
-GPU, and every transition (with its priority) is delivered to the HOST replay ring: RCCL gather of
-the packed blocks to rank 0 over xGMI every --flush steps, then rank 0's copy stream drains each
-gathered slot to pinned host memory.  The rate with the ring kept in rank 0's HBM is measured right
-after and reported beside it (`hbm_ring`).
+Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on: 65 536 lattices, d=7,
+p_error=0.10.  Lattices are resident in HBM when the timed region starts; nothing crosses PCIe in the N=1 loop.
+Set-up, untimed, per leg: (1) burn-in -- the episodes are staggered (lattice e is reset at step e mod 76), so the population
+and with it perspectives per lattice is stationary and `value` does not depend on --steps; (2) the stack-buffer probe
+(EnvSet.pickStackBuffer: --stack-candidates buffers, all allocated first, the write timed inside the loop, the fastest
+kept; on MI355X a buffer has a write rate of its own); (3) 64 passes of the loop in one go (the ~25 passes after the
+bursty probe run 2-3 % slower: profiles/r04_first_steps_after_setup.txt).  Then W warm-up passes (their writes are held
+against the probe: > 8 % slower -> one re-probe; plus at most flush-1 passes so that the timed region starts on a
+transition-block boundary on every rank), barrier + synchronize, exactly K timed passes, barrier + synchronize.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (perspective write
-kernel, HIP events around every launch in the timed region), `cpu_baseline` (the C oracle's actor
-loop on the host cores, rank 0, N=1 only) and `nn_in_loop` (configs[2] as written: the stack fed
-to NN_11 and device-side selection in the loop; N=1 only, --nn-steps 0 to skip).
+N>1: `python bench.py --gpus N` starts N ranks by itself (a `python -m torch.distributed.run` child, before this process
+touches the GPU) and relays rank 0's JSON line; under torch.distributed.run (WORLD_SIZE set) it runs as a rank.  One rank
+per GPU; every rank owns a contiguous block of global env ids (weak scaling).  Default shape for N>1: BASELINE.json
+configs[4] -- 131 072 lattices per GPU, and every transition (with its priority) is delivered to the HOST replay ring:
+RCCL gather of the packed blocks to rank 0 over xGMI every --flush steps (issued from stream B right behind the
+priorities), then rank 0's copy stream drains each gathered slot to pinned host memory.  The rate with the ring kept in
+rank 0's HBM is measured right after and reported beside it (`hbm_ring`); `ranks[]` carries every rank's own roofline.
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Every leg -- the headline, `configs4_shard_on_one_gpu`,
+`bf16_stack`, `configs3_on_one_gpu.{one_shot,chunks_4}` -- carries `stack_buffer_probe`, `stack_verified` (the timed buffer
+holds the right bytes; a failure voids the line) and its own `roofline` (HIP events on the write's stream around every
+--event-every-th write; `probe_ms_chosen`, `timed_write_ms`, `timed_over_probe`, `default_buffer`); `cpu_baseline` (the
+oracle's ports on the host cores, rank 0, N=1 only) and `nn_in_loop` (configs[2] as written: the stack fed to NN_11 and
+device-side selection in the loop; N=1 only, --nn-steps 0 to skip).  --shards > 1, --graph and --policy nn11 take the
+serial path (run_serial).
 """
 import argparse
 import contextlib

@@ -137,7 +137,9 @@ int tq_eval_ground_state(tq_env* h, uint8_t* out, void* stream);
 int tq_is_terminal(tq_env* h, uint8_t* out, void* stream);
 
 /* generatePerspectiveBatch, step 1 (numba/util_actor.py:56-67 + cumsum :35): counts i32[N]
- * (may be NULL) and offsets i64[N+1] (exclusive scan, offsets[N] = P). */
+ * (may be NULL) and offsets i64[N+1] (exclusive scan, offsets[N] = P).  A by-product are the cut points of the batch
+ * into 256 parts of equal perspective count that tq_persp_write(the same `offsets` pointer) uses; the handle keeps the
+ * tables of the last TWO calls (a write that is still running on another stream reads the older one). */
 int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream);
 /* generatePerspectiveBatch + np.concatenate, step 2 (numba/util_actor.py:33-39): writes the
  * env-major stack out[P,2,d,d] of element type `dtype` and positions i32[P,3] (may be NULL)

@@ -8,9 +8,10 @@
 //     that is the workgroup's output range as a bit string (bit x = element org + x of the stack);
 //   * NS storer waves do nothing but  ds_read_b32 -> shift -> bit->element expansion -> global_store_dwordx4
 //     along that range, in aligned windows of CPW KiB, and hand the ring words back zeroed;
-//   * one wave writes the positions (P,3) from a second ring (one packed dword per perspective).
-// Hand-off: `pq[p]` (producer p: first perspective of the lattice it is working on -- its earlier lattices are in the
-// rings; the minimum over the producers is the produced PREFIX of the range, no producer ever waits for another),
+//   * NPW positions waves write the positions (P,3) from a second ring (one packed dword per perspective).
+// Hand-off: `pq[p]` (producer p: how far it is -- the first perspective of its lattice that is not in the rings yet,
+// published per lattice and after every pass of 64 hits inside a lattice; its earlier lattices are complete; the
+// minimum over the producers is the produced PREFIX of the range, no producer ever waits for another),
 // `cons[s]` (low-water mark of storer s), `pcons[w]` (of positions wave w): plain LDS words, polled with s_sleep.
 // Every poll loop is bounded; a wave that gives up raises `abort` for its workgroup and latches ERR_INTERNAL, so the
 // grid always drains.
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offse
 }
 
 // STATS (diagnostic builds only, tools/stream_bench.hip): every wave leaves {cycles alive, cycles waiting (A), cycles
-// waiting (B), items} in stats[(block * waves + wave) * 4 ..]; A/B = storers: production / -, producers: ring room / commit turn.
+// waiting (B), items} in stats[(block * waves + wave) * 4 ..]; A/B = storers: production / -, producers: ring room / - (until round 3: commit turn).
 // NPW: positions waves (chunks of 1 KiB dealt round-robin among them)
 template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false, int NPW = 1>
 __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uint64_t* __restrict__ vp, int64_t N,

@@ -260,14 +260,23 @@ class Shard:
     --shards > 1, --graph, --policy nn11)."""
 
 
-def hbm_roofline(alg_bytes, write_ms, extra=None):
-    """The `roofline` object of one leg: algorithmic bytes per launch over the stack write's average
-    duration from HIP events on the stream the kernel runs on."""
-    ms = float(np.mean(write_ms))
+def hbm_roofline(alg_bytes, write_ms, extra=None, first_of=None):
+    """The `roofline` object of one leg: algorithmic bytes per launch over the stack write's average duration
+    from HIP events on the stream the kernel runs on.  ``first_of`` = K: write_ms[0] is the FIRST launch of a timed
+    region of K launches (the first kernel on its stream after the barrier: a few per cent slower) and the others a
+    regular sample of the remaining K - 1; the average over all K launches is estimated with those weights -- the first
+    launch counts 1 / K, not 1 / (number of samples)."""
+    write_ms = np.ravel(np.asarray(write_ms, dtype=np.float64))
+    if first_of is not None and write_ms.size > 1 and first_of > 1:
+        ms = float((write_ms[0] + (first_of - 1) * write_ms[1:].mean()) / first_of)
+    else:
+        ms = float(write_ms.mean())
     ach = alg_bytes / (ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": STACK_KERNEL, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-         "bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "median_launch_ms": float(np.median(write_ms)), "launches_timed": int(np.size(write_ms)),
-         "first_launches_ms": [round(float(x), 4) for x in np.ravel(write_ms)[:(100000 if os.environ.get("TORIC_BENCH_SERIES") == "1" else 8)]]}
+         "bytes_per_launch": alg_bytes, "avg_launch_ms": ms, "median_launch_ms": float(np.median(write_ms)), "launches_timed": int(write_ms.size),
+         "first_launches_ms": [round(float(x), 4) for x in write_ms[:(100000 if os.environ.get("TORIC_BENCH_SERIES") == "1" else 8)]]}
+    if first_of is not None:
+        r["first_launch_ms"] = float(write_ms[0])
     if extra:
         r.update(extra)
     return r
@@ -364,7 +373,9 @@ class ExploreLeg:
         torch = self.torch
         self.K, self.every = K, max(1, min(every, K))
         assert self.offs.shape[0] > K + 1, "one offsets row per timed step"
-        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((K + self.every - 1) // self.every)]
+        # which launches are bracketed: the first one, and the middle launch of every further group of `every`
+        self.sampled = list(range(K)) if self.every == 1 else [0] + [i for i in range(1, K) if i % self.every == self.every // 2]
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in self.sampled]
         for a, b in self.ev:
             a.record(self.loop.A)
             b.record(self.loop.A)
@@ -375,16 +386,17 @@ class ExploreLeg:
         if self.K != K or self.every != max(1, min(every, K)) or not self.ev:
             self.prepare(K, every)
         self.t0 = self.loop.t
+        at = {i: j for j, i in enumerate(self.sampled)}
         for i in range(K):
-            self.loop.step(self.ev[i // self.every] if i % self.every == 0 else None)
+            self.loop.step(self.ev[at[i]] if i in at else None)
         self.loop.drain()
 
     def perspectives(self):
-        """(P of every timed step, f64 tensor; mean P of the bracketed steps)."""
+        """(P of every timed step, f64 tensor; mean P over ALL timed steps -- the scan's row of every step is kept)."""
         R = self.offs.shape[0]
         rows = self.torch.tensor([(self.t0 + i) % R for i in range(self.K)], device=self.device)
         p = self.offs[rows, self.n].to(self.torch.float64)
-        return p, float(p[::self.every].mean().item())
+        return p, float(p.mean().item())
 
     def write_ms(self):
         return np.array([a.elapsed_time(b) for a, b in self.ev])
@@ -395,16 +407,20 @@ class ExploreLeg:
         ms = self.write_ms()
         r = hbm_roofline(alg, ms, {"perspectives_per_launch": p_mean / self.chunks, "launches_per_step": self.chunks,
                                    "lattices_per_launch": self.n // self.chunks, "bytes_per_step": alg,
-                                   "timed_launches": "HIP events on the write's stream around the stack write(s) of every %d. timed step%s" % (
-                                       self.every, "" if self.chunks == 1 else ": the %d range launches and their gaps included" % self.chunks)})
+                                   "timed_launches": "HIP events on the write's stream around the stack write(s) of the first timed step and of the middle "
+                                                     "step of every further group of %d (%d of %d steps); avg_launch_ms estimates the mean over ALL %d: "
+                                                     "(first + (K-1) * mean(others)) / K%s" % (
+                                       self.every, len(self.sampled), self.K, self.K,
+                                       "" if self.chunks == 1 else "; the %d range launches of a step and their gaps included" % self.chunks)},
+                         first_of=self.K)
         if self.chunks > 1:
             r["bytes_per_launch"] = alg / self.chunks
         if self.probe is not None:
             r["probe_ms_chosen"] = self.probe["probe_ms_chosen"]
-            r["timed_write_ms"] = float(ms.mean())
-            r["timed_over_probe"] = float(ms.mean()) / self.probe["probe_ms_chosen"]
+            r["timed_write_ms"] = r["avg_launch_ms"]
+            r["timed_over_probe"] = r["avg_launch_ms"] / self.probe["probe_ms_chosen"]
             r["default_buffer"] = {"kind": self.probe["kinds"][0], "write_ms": self.probe["write_ms"][0],
-                                   "frac": r["frac"] * float(ms.mean()) / self.probe["write_ms"][0],
+                                   "frac": r["frac"] * r["avg_launch_ms"] / self.probe["write_ms"][0],
                                    "note": "candidate 0 of the probe: what a caller gets without pickStackBuffer (same loop, probe's clock)"}
         if extra:
             r.update(extra)

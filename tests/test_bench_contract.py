@@ -29,6 +29,9 @@ def test_roofline_arithmetic_and_config_names():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches_timed"] == 3
     assert abs(r["achieved"] - alg / 0.29e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert r["median_launch_ms"] == 0.29 and r["bytes_per_launch"] == alg and r["probe_ms_chosen"] == 0.29
+    # the first launch of a region of K counts 1/K, the regular sample of the others (K-1)/K
+    w = bench.hbm_roofline(alg, [0.32, 0.29, 0.30, 0.28], first_of=20)
+    assert abs(w["avg_launch_ms"] - (0.32 + 19 * 0.29) / 20) < 1e-12 and w["first_launch_ms"] == 0.32 and w["launches_timed"] == 4
     assert bench.config_name(1, 65536, 7, 0.10) == "configs[2]" and bench.config_name(1, 65536, 9, 0.15) == "configs[3]"
     assert bench.config_name(8, 131072, 7, 0.10) == "configs[4] shape" and bench.config_name(1, 8192, 7, 0.10) == "custom"
     assert bench.config_name(1, 4096, 5, 0.10) == "configs[1]"
@@ -128,7 +131,7 @@ def test_bench_json_contract():
     assert pr["kinds"][0] == "torch.empty" and len(pr["write_ms"]) == pr["candidates"] >= 2 and 0 <= pr["chosen"] < pr["candidates"]
     assert pr["writes_per_candidate"] >= 10 and abs(pr["probe_ms_chosen"] - pr["write_ms"][pr["chosen"]]) < 1e-9 or "reprobe" in pr
     # every leg explains itself: what the probe promised, what the timed region delivered, what a default allocation would give
-    assert r["probe_ms_chosen"] > 0 and abs(r["timed_write_ms"] - r["avg_launch_ms"]) < 1e-9
+    assert r["probe_ms_chosen"] > 0 and abs(r["timed_write_ms"] - r["avg_launch_ms"]) < 1e-9 and r["first_launch_ms"] > 0
     assert abs(r["timed_over_probe"] - r["timed_write_ms"] / r["probe_ms_chosen"]) < 1e-9
     assert r["default_buffer"]["kind"] == "torch.empty" and 0 < r["default_buffer"]["frac"] <= 1.0
     assert set(j["probe_vs_timed"]) == {"headline"} and isinstance(j["legs_outside_3pct_of_probe"], list)

@@ -448,6 +448,9 @@ class ExploreLeg:
                        "a fresh torch.empty buffer, compared byte for byte"}
 
     def close(self):
+        if self.loop is not None:
+            self.loop.drain()
+        self.torch.cuda.synchronize(self.device)       # nothing of the side stream may still run when the handle goes
         self.envs.check()
         self.envs.close()                       # frees the parked candidates of the probe as well ...
         self.loop = None

@@ -148,8 +148,12 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
     constexpr int LPD = 32 / VEC;                            // lanes that share one ring dword
     constexpr uint32_t RING_BITS = 32u << RB_LOG, BMASK = (1u << RB_LOG) - 1u;
     constexpr uint32_t RP = 1u << RP_LOG, PMASK = RP - 1u;
-    // a producer asks for ring room one pass of 64 hits at a time and publishes its progress after every pass, so the ring
-    // has to hold one pass plus what the storers may lag behind -- not a whole lattice (2d^2 hits of 2d^2 bits each)
+    // WHOLE: a lattice's whole stack (2d^2 hits of 2d^2 bits each at most) fits into the ring beside what the storers may lag
+    // behind: the producer asks for room once per lattice.  Otherwise (d >= 19) it asks pass by pass (64 hits) and publishes its
+    // progress after every pass -- the consumers must be able to take the first passes of a lattice for the last ones to find
+    // room.  Per-pass publishing costs a producer ~14 % (an LDS drain and a publish per pass: 5290 against 4640 cycles per d=7
+    // lattice, profiles/r04_stream_tune_ab_passes.txt), so it is used only where it is needed.
+    constexpr bool WHOLE = (uint32_t)NQ * NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS;
     static_assert(64u * (uint32_t)NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS, "bit ring too small for this lattice size");
     static_assert((uint32_t)NQ + 512u < RP, "position ring too small");
     __shared__ StreamLds<D, NS, NP, RB_LOG, RP_LOG, NPW> S;
@@ -454,9 +458,9 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
             lds_publish(S.pq[p], q0, lane);
             // ---- room in the rings: everything below the storers' low-water mark has been handed back.  The marks
             // are cached: while the storers keep up the ring is nearly empty and one look lasts for dozens of lattices.
-            // Positions: the whole lattice (n <= 2d^2 < ring - 512); bits: the first pass of 64 hits (later passes below).
+            // Positions: the whole lattice (n <= 2d^2 < ring - 512); bits: the whole lattice, or (d >= 19) its first pass of 64 hits.
             if (STATS) ++n_items;
-            const uint32_t pass1 = (uint32_t)(n < 64 ? n : 64);
+            const uint32_t pass1 = (uint32_t)((WHOLE || n < 64) ? n : 64);
             if (!wait_room(bit0 + pass1 * (uint32_t)NQ, q0 + (uint32_t)n)) return;
             // ---- tables: rotated planes (ballot), row-rolled planes, hit list
             B rv, rp;
@@ -488,11 +492,11 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                 }
             }
             wave_lds_sync();
-            // ---- one lane per hit, 64 hits per pass: its perspective as two bit-planes, OR-ed into the ring.  After every pass
-            // the wave says how far the lattice is (the consumers may take it) and asks for the next pass's room: a lattice
-            // never has to fit into the ring as a whole (d >= 19: 2d^2 hits x 2d^2 bits are more than the ring holds)
+            // ---- one lane per hit, 64 hits per pass: its perspective as two bit-planes, OR-ed into the ring.  d >= 19 (!WHOLE):
+            // after every pass the wave says how far the lattice is (the consumers may take it) and asks for the next pass's
+            // room -- 2d^2 hits x 2d^2 bits are more than the ring holds
             for (int kb = 0; kb < n; kb += 64) {
-                if (kb) {
+                if (!WHOLE && kb) {
                     lds_publish(S.pq[p], q0 + (uint32_t)kb, lane);
                     const uint32_t upto = (uint32_t)(n < kb + 64 ? n : kb + 64);
                     if (!wait_room(bit0 + upto * (uint32_t)NQ, q0 + (uint32_t)n)) return;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                 const uint32_t hp = T.hpos[k];
                 const int layer = (int)(hp & 255u), i = (int)((hp >> 8) & 255u), jj = (int)(hp >> 16);
                 int rs, cs;
-                PS::hit_shifts(layer, i, jj, rs, cs);
+                PS::hit_shifts(layer, i, jj, rs, cs);           // (moving this to the hit-list stage, per qubit lane, was measured: no gain)
                 B a, c, low;
 #pragma unroll
                 for (int w = 0; w < W; ++w) { a.w[w] = T.rr[2 * layer][rs][w]; c.w[w] = T.rr[2 * layer + 1][rs][w]; low.w[w] = T.low[cs][w]; }

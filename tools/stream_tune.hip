@@ -79,11 +79,11 @@ struct Ctx {
 
 // GRID: workgroups (a power of two; 256 = one per CU with the scan's cut points, 512 = two per CU -- needs <= 80 KB of LDS --
 // which find their cut points themselves)
-template <int D, typename OutT, int NS, int NPW, int NP, int CPW, int RB, int RP, int GRID = 256>
+template <int D, typename OutT, int NS, int NPW, int NP, int CPW, int RB, int RP, int GRID = 256, int QS = 1>
 void one(Ctx& c, bool stats, bool is_ref) {
     constexpr int WV = NS + NPW + NP;
     const int32_t* sp = GRID == 256 ? c.split : nullptr;
-    auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, false, NPW>), dim3(GRID), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
+    auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, false, NPW, QS>), dim3(GRID), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
                                       (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, sp, (unsigned long long*)nullptr); };
     CK(hipMemset(c.out, 0x77, c.out_bytes)); CK(hipMemset(c.pos, 0x77, (size_t)c.P * 12));
     k(); CK(hipDeviceSynchronize());
@@ -99,14 +99,14 @@ void one(Ctx& c, bool stats, bool is_ref) {
     int e; CK(hipMemcpy(&e, c.err, 4, hipMemcpyDeviceToHost));
     float a = 0, mn = 1e9;
     for (int r = 0; r < 9; ++r) { float x = c.t->run(k); if (r) { a += x; mn = std::min(mn, x); } }
-    printf("  grid %d NS=%d NPW=%d NP=%2d CPW=%2d ring 2^%d/2^%d  %7.1f us  %6.0f GB/s (best %6.0f)   %s, latch %d\n", GRID, NS, NPW, NP, CPW, RB, RP, 1e3 * a / 8,
+    printf("  grid %d NS=%d NPW=%d NP=%2d CPW=%2d QS=%d ring 2^%d/2^%d  %7.1f us  %6.0f GB/s (best %6.0f)   %s, latch %d\n", GRID, NS, NPW, NP, CPW, QS, RB, RP, 1e3 * a / 8,
            c.bytes / (a / 8) / 1e6, c.bytes / mn / 1e6, is_ref ? "reference of this sweep" : (nb ? "DIFFERS" : "same bytes"), e);
     if (nb) printf("      %llu differing dwords\n", nb);
     if (!stats || GRID != 256) return;
     unsigned long long* st;
     CK(hipMalloc(&st, sizeof(unsigned long long) * 256 * WV * 4));
     CK(hipMemset(st, 0, sizeof(unsigned long long) * 256 * WV * 4));
-    hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, true, NPW>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off, (OutT*)c.out, c.pos, c.P,
+    hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, true, NPW, QS>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off, (OutT*)c.out, c.pos, c.P,
                        c.err, (int64_t)0, c.N, c.split, st);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)256 * WV * 4);
@@ -177,39 +177,43 @@ int run(int64_t N, double q, const char* tname) {
     printf("  -> buffer %d\n", best);
     c.out = bufs[best];
 #define CFG(NS, NPW, NP, CPW, STATS, REF) one<D, OutT, NS, NPW, NP, CPW, 14, 12>(c, STATS, REF);
-    if (D <= 5) {
-        CFG(2, 1, 13, 8, true, true)
-        CFG(4, 1, 11, 8, true, false)
-        CFG(4, 1, 11, 4, false, false)
-        CFG(4, 2, 10, 8, true, false)
-        CFG(3, 1, 12, 8, false, false)
-        CFG(3, 2, 11, 8, false, false)
-        CFG(2, 2, 12, 8, false, false)
-        CFG(2, 1, 13, 8, false, false)
-        // two workgroups per CU (32 KB bit ring, 8 KB position ring): twice the producers per CU
-        one<D, OutT, 2, 1, 13, 8, 13, 11, 512>(c, false, false);
-        one<D, OutT, 2, 2, 12, 8, 13, 11, 512>(c, false, false);
-        one<D, OutT, 2, 1, 13, 4, 13, 11, 512>(c, false, false);
-        one<D, OutT, 2, 1, 13, 8, 13, 11, 256>(c, false, false);
-    } else if (D >= 13) {
+#define CFQ(NS, NPW, NP, QS, STATS, REF) one<D, OutT, NS, NPW, NP, 8, 14, 12, 256, QS>(c, STATS, REF);
+    if constexpr (D == 3) {
+        CFQ(2, 1, 13, 1, true, true)
+        CFQ(2, 1, 13, 8, true, false)
+        CFQ(2, 1, 13, 4, false, false)
+        CFQ(3, 1, 12, 8, false, false)
+        CFQ(4, 1, 11, 8, false, false)
+        CFQ(2, 2, 12, 8, false, false)
+        CFQ(2, 1, 13, 1, false, false)
+    } else if constexpr (D == 5) {
+        CFQ(2, 1, 13, 1, true, true)
+        CFQ(2, 1, 13, 4, true, false)
+        CFQ(2, 2, 12, 1, false, false)
+        CFQ(2, 2, 12, 4, true, false)
+        CFQ(3, 2, 11, 1, false, false)
+        CFQ(3, 2, 11, 4, false, false)
+        CFQ(4, 2, 10, 4, false, false)
+        CFQ(4, 1, 11, 4, false, false)
+        CFQ(2, 1, 13, 1, false, false)
+    } else if constexpr (D >= 13) {
         CFG(4, 1, 7, 8, true, true)
-        CFG(4, 1, 5, 8, false, false)
-        CFG(4, 1, 4, 8, false, false)
         CFG(4, 1, 3, 8, true, false)
-        CFG(4, 1, 2, 8, false, false)
-        CFG(4, 2, 3, 8, false, false)
         CFG(4, 2, 6, 8, ES < 4, false)
-        CFG(4, 2, 10, 8, ES < 4, false)
-        CFG(4, 1, 11, 8, false, false)
         CFG(4, 1, 7, 8, false, false)
+    } else if constexpr (D == 7) {
+        CFQ(4, 1, 11, 1, true, true)
+        CFQ(4, 1, 11, 3, true, false)
+        CFQ(4, 2, 10, 1, true, false)
+        CFQ(4, 2, 10, 3, true, false)
+        CFQ(4, 2, 10, 4, false, false)
+        CFQ(3, 2, 11, 3, false, false)
+        CFQ(4, 1, 7, 3, false, false)
+        CFQ(4, 1, 11, 1, false, false)
     } else {
         CFG(4, 1, 11, 8, true, true)
         CFG(4, 2, 10, 8, true, false)
-        CFG(4, 2, 10, 4, false, false)
         CFG(4, 3, 9, 8, false, false)
-        CFG(4, 1, 7, 8, false, false)
-        CFG(4, 2, 6, 8, false, false)
-        CFG(3, 2, 11, 8, false, false)
         CFG(4, 1, 11, 8, false, false)
     }
     return 0;

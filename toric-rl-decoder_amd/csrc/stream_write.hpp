@@ -63,18 +63,28 @@ __device__ __forceinline__ void emit_at(uint32_t pos, const typename Lat<D>::B& 
 }
 
 template <int D>
-struct ProdTables {                                            // private to one producer wave
+struct LatTables {                                             // of ONE lattice
     static constexpr int NQP = (Lat<D>::NQ + 7) & ~7;
     uint64_t rr[4][D][Lat<D>::W];                              // V, P, rot V, rot P rolled by every row amount
-    uint64_t low[D][Lat<D>::W];                                // lowcols(k)
     uint32_t hpos[NQP];                                        // k-th hit -> layer | row << 8 | col << 16
 };
+// private to one producer wave.  QS = 1: one lattice at a time, its hits done in passes of 64 lanes (a lattice of 73 hits
+// pays for two passes).  QS > 1 (small lattices): the hits of CONSECUTIVE lattices are queued and done 64 at a time whichever
+// lattice they belong to -- a d=3 lattice has 16 hits, a d=7 lattice 73 -- so up to QS lattices' tables are alive at once.
+template <int D, int QS>
+struct ProdTables {
+    static constexpr int QN = QS == 1 ? 1 : (Lat<D>::NQ + 63 <= 128 ? 128 : 256);   // queue entries: < 64 waiting + one lattice's, power of two
+    LatTables<D> t[QS];
+    uint64_t low[D][Lat<D>::W];                                // lowcols(k): the same for every lattice
+    uint32_t qent[QN];                                         // queued hit: number of its lattice (16 bits; slot = number % QS) << 16 | index of the hit in its lattice
+    uint32_t qq[QN];                                           //             its perspective (range-relative)
+};
 
-template <int D, int NS, int NP, int RB_LOG, int RP_LOG, int NPW = 1>
+template <int D, int NS, int NP, int RB_LOG, int RP_LOG, int NPW = 1, int QS = 1>
 struct StreamLds {
     __attribute__((aligned(16))) uint32_t bits[1u << RB_LOG];  // the output range as a bit string, ring
     uint32_t posr[1u << RP_LOG];                               // packed position of perspective q at [q & mask]
-    ProdTables<D> tab[NP];
+    ProdTables<D, QS> tab[NP];
     uint32_t pq[NP];                                           // producer p: first perspective (range-relative) of the lattice it is
                                                                // working on; everything of ITS lattices below that is in the rings;
                                                                // 0xFFFFFFFF = it has no lattice left
@@ -122,7 +132,8 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offse
 // STATS (diagnostic builds only, tools/stream_bench.hip): every wave leaves {cycles alive, cycles waiting (A), cycles
 // waiting (B), items} in stats[(block * waves + wave) * 4 ..]; A/B = storers: production / -, producers: ring room / - (until round 3: commit turn).
 // NPW: positions waves (chunks of 1 KiB dealt round-robin among them)
-template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false, int NPW = 1>
+// QS: lattices whose tables a producer keeps alive (1 = one lattice at a time; > 1 = hit queue across lattices, d <= 7)
+template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false, int NPW = 1, int QS = 1>
 __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uint64_t* __restrict__ vp, int64_t N,
                                                                   const int64_t* __restrict__ offsets, OutT* __restrict__ out,
                                                                   int32_t* __restrict__ pos, int64_t capacity,
@@ -156,7 +167,9 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
     constexpr bool WHOLE = (uint32_t)NQ * NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS;
     static_assert(64u * (uint32_t)NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS, "bit ring too small for this lattice size");
     static_assert((uint32_t)NQ + 512u < RP, "position ring too small");
-    __shared__ StreamLds<D, NS, NP, RB_LOG, RP_LOG, NPW> S;
+    static_assert(QS == 1 || (uint32_t)NQ + 63u <= (uint32_t)ProdTables<D, QS>::QN, "hit queue too small");
+    static_assert(QS == 1 || (uint32_t)NQ * NQ + 2u * NS * CPW * EPC + 4096u < RING_BITS, "the hit queue needs lattices that fit the ring whole");
+    __shared__ StreamLds<D, NS, NP, RB_LOG, RP_LOG, NPW, QS> S;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
@@ -385,20 +398,21 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
 
     // =============================================================== producer
     const int p = wave - NS - NPW;
-    ProdTables<D>& T = S.tab[p];
+    ProdTables<D, QS>& PT = S.tab[p];
     if (lane < D) {                                          // column masks: the same for every lattice
         const B m = L::lowcols(lane);
 #pragma unroll
-        for (int w = 0; w < W; ++w) T.low[lane][w] = m.w[w];
+        for (int w = 0; w < W; ++w) PT.low[lane][w] = m.w[w];
     }
     const int64_t QT = Q1 + need_extra;                      // lattices are produced while they start in front of QT
     uint32_t lw_c = a0, pc_c = 0u;                           // cached low-water marks of the storers
     // wait until the rings have room for the stream bits below `bits_end` and the positions below `q_end`; wave-uniform;
     // false = the workgroup gave up (the caller returns)
-    auto wait_room = [&](uint32_t bits_end, uint32_t q_end) -> bool {
-        auto fits = [&]() {
-            return (lw_c == 0xFFFFFFFFu || bits_end + 64u <= lw_c + RING_BITS) && (!has_pos || pc_c == 0xFFFFFFFFu || q_end <= pc_c + RP);
-        };
+    auto room_now = [&](uint32_t bits_end, uint32_t q_end) __attribute__((always_inline)) -> bool {       // by the cached marks
+        return (lw_c == 0xFFFFFFFFu || bits_end + 64u <= lw_c + RING_BITS) && (!has_pos || pc_c == 0xFFFFFFFFu || q_end <= pc_c + RP);
+    };
+    auto wait_room = [&](uint32_t bits_end, uint32_t q_end) __attribute__((always_inline)) -> bool {
+        auto fits = [&]() { return room_now(bits_end, q_end); };
         if (fits()) return true;
         unsigned long long t0 = 0;
         if (STATS) t0 = __builtin_readcyclecounter();
@@ -426,6 +440,78 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
         give_up();
         return false;
     };
+    // tables of one lattice: rotated planes (ballot), row-rolled planes, hit list (+ its positions, + its queue entries)
+    auto build = [&](LatTables<D>& T, const B& v, const B& pl, const B& e0, const B& e1, int n0, uint32_t q0, uint32_t seq, uint32_t qtail) __attribute__((always_inline)) {
+        B rv, rp;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int o = 64 * k + lane;
+            const bool inb = o < DD;
+            const int oc = inb ? o : 0;
+            rv.w[k] = __ballot(inb && v.get(PS::rot_src_v(oc)));
+            rp.w[k] = __ballot(inb && pl.get(PS::rot_src_p(oc)));
+        }
+        for (int t = lane; t < 4 * D; t += 64) {             // one lane per (plane, row amount): 4 d entries (more than 64 from d = 17 on)
+            const int sel = t / D, k = t - sel * D;
+            B src;
+#pragma unroll
+            for (int w = 0; w < W; ++w) src.w[w] = sel == 0 ? v.w[w] : (sel == 1 ? pl.w[w] : (sel == 2 ? rv.w[w] : rp.w[w]));
+            const B r = (src.shl(k * D) | src.shr(DD - k * D)) & L::full();
+#pragma unroll
+            for (int w = 0; w < W; ++w) T.rr[sel][k][w] = r.w[w];
+        }
+        for (int c = lane; c < NQ; c += 64) {
+            const int l = c >= DD, bit = c - l * DD;
+            if (l ? e1.get(bit) : e0.get(bit)) {
+                const int row = bit / D, col = bit - row * D;
+                const int k = l ? n0 + e1.rank(bit) : e0.rank(bit);
+                const uint32_t hp = (uint32_t)l | ((uint32_t)row << 8) | ((uint32_t)col << 16);
+                T.hpos[k] = hp;
+                if (has_pos) S.posr[(q0 + (uint32_t)k) & PMASK] = hp;
+                if (QS > 1) {
+                    constexpr uint32_t QMASK = (uint32_t)ProdTables<D, QS>::QN - 1u;
+                    PT.qent[(qtail + (uint32_t)k) & QMASK] = (seq << 16) | (uint32_t)k;
+                    PT.qq[(qtail + (uint32_t)k) & QMASK] = q0 + (uint32_t)k;
+                }
+            }
+        }
+    };
+    // one hit: its perspective as two bit-planes (two row-rolled planes of its lattice's table, two masked column rolls),
+    // OR-ed into the ring at perspective q
+    auto emit_hit = [&](const LatTables<D>& T, int k, uint32_t q) __attribute__((always_inline)) {
+        const uint32_t hp = T.hpos[k];
+        const int layer = (int)(hp & 255u), i = (int)((hp >> 8) & 255u), jj = (int)(hp >> 16);
+        int rs, cs;
+        PS::hit_shifts(layer, i, jj, rs, cs);                // (moving this to the hit-list stage, per qubit lane, was measured: no gain)
+        B a, c, low;
+#pragma unroll
+        for (int w = 0; w < W; ++w) { a.w[w] = T.rr[2 * layer][rs][w]; c.w[w] = T.rr[2 * layer + 1][rs][w]; low.w[w] = PT.low[cs][w]; }
+        const B ov = PS::roll_cols_masked(a, cs, low), op = PS::roll_cols_masked(c, cs, low);
+        if (has_stack)
+            emit_at<D>(head + q * (uint32_t)NQ, ov, op, [&](uint32_t idx, uint32_t val) { atomicOr(&S.bits[idx & BMASK], val); });
+    };
+    // ---- the hit queue (QS > 1): wave-uniform state, as little of it as possible (the kernel sits at the SGPR limit)
+    uint32_t qh = 0, qn = 0;                                 // head of the queue, hits waiting in it
+    uint32_t seq_new = 0, seq_head = 0;                      // lattices queued so far / the lattice of the hit at the head
+    // the first cnt (<= 64) waiting hits, one lane each; then say how far this wave is: everything of ITS lattices below the
+    // perspective after the last hit done is in the rings (its next hit is that very perspective or lies further on)
+    auto emit_pass = [&](uint32_t cnt) __attribute__((always_inline)) {
+        constexpr uint32_t QMASK = (uint32_t)ProdTables<D, QS>::QN - 1u;
+        uint32_t q = 0;
+        const uint32_t e_next = PT.qent[(qh + cnt) & QMASK]; // the hit that will be at the head afterwards (if any)
+        if ((uint32_t)lane < cnt) {
+            const uint32_t at = (qh + (uint32_t)lane) & QMASK;
+            const uint32_t e = PT.qent[at];
+            q = PT.qq[at];
+            emit_hit(PT.t[QS > 1 ? ((e >> 16) % (uint32_t)QS) : 0], (int)(e & 0xFFFFu), q);
+        }
+        const uint32_t done = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)cnt - 1) + 1u;
+        lds_publish(S.pq[p], done, lane);
+        qh += cnt; qn -= cnt;
+        seq_head = qn ? ((uint32_t)__builtin_amdgcn_readfirstlane((int)e_next) >> 16) : seq_new;
+    };
+    auto flush = [&]() __attribute__((always_inline)) { while (qn) emit_pass(qn < 64u ? qn : 64u); };
+
     for (int64_t Lb = 0;; Lb += 64 * NP) {
         // the planes and offsets of this wave's next 64 lattices in one round of vector loads
         const int64_t e_l = e_lo + Lb + (int64_t)lane * NP + p;
@@ -454,47 +540,40 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
             if (n == 0) continue;
             const uint32_t q0 = (uint32_t)((int64_t)readlane64((uint64_t)oo, j) - Q0);
             const uint32_t bit0 = head + q0 * (uint32_t)NQ;
-            // this wave's earlier lattices are in the rings (its LDS operations execute in issue order): say so
-            lds_publish(S.pq[p], q0, lane);
-            // ---- room in the rings: everything below the storers' low-water mark has been handed back.  The marks
-            // are cached: while the storers keep up the ring is nearly empty and one look lasts for dozens of lattices.
-            // Positions: the whole lattice (n <= 2d^2 < ring - 512); bits: the whole lattice, or (d >= 19) its first pass of 64 hits.
             if (STATS) ++n_items;
+            if (QS > 1) {
+                // ---- hit queue: a table slot (the oldest lattices give theirs back as their hits get done; if all are taken
+                // the waiting hits are done now, in a short pass), ring room for the whole lattice -- this wave WAITS only
+                // with an empty queue: hits it holds back keep the consumers from the very room it would wait for
+                if (((seq_new - seq_head) & 0xFFFFu) >= (uint32_t)QS) flush();   // (16-bit lattice numbers in the queue entries)
+                if (!room_now(bit0 + (uint32_t)n * NQ, q0 + (uint32_t)n)) {
+                    flush();
+                    if (!wait_room(bit0 + (uint32_t)n * NQ, q0 + (uint32_t)n)) return;
+                }
+                if (qn == 0) lds_publish(S.pq[p], q0, lane);    // nothing older waits: this lattice is how far the wave is
+                const uint32_t slot = seq_new % (uint32_t)QS;
+                if (qn == 0) seq_head = seq_new;
+                build(PT.t[slot], v, pl, e0, e1, n0, q0, seq_new, qh + qn);
+                seq_new = (seq_new + 1u) & 0xFFFFu;
+                qn += (uint32_t)n;
+                wave_lds_sync();
+                while (qn >= 64u) emit_pass(64u);
+                wave_lds_sync();                             // a slot given back is rewritten by a later lattice
+                continue;
+            }
+            // ---- one lattice at a time.  This wave's earlier lattices are in the rings (its LDS operations execute in issue
+            // order): say so
+            lds_publish(S.pq[p], q0, lane);
+            // room in the rings: everything below the storers' low-water mark has been handed back.  The marks are cached:
+            // while the storers keep up the ring is nearly empty and one look lasts for dozens of lattices.  Positions: the
+            // whole lattice (n <= 2d^2 < ring - 512); bits: the whole lattice, or (d >= 19) its first pass of 64 hits.
             const uint32_t pass1 = (uint32_t)((WHOLE || n < 64) ? n : 64);
             if (!wait_room(bit0 + pass1 * (uint32_t)NQ, q0 + (uint32_t)n)) return;
-            // ---- tables: rotated planes (ballot), row-rolled planes, hit list
-            B rv, rp;
-#pragma unroll
-            for (int k = 0; k < W; ++k) {
-                const int o = 64 * k + lane;
-                const bool inb = o < DD;
-                const int oc = inb ? o : 0;
-                rv.w[k] = __ballot(inb && v.get(PS::rot_src_v(oc)));
-                rp.w[k] = __ballot(inb && pl.get(PS::rot_src_p(oc)));
-            }
-            for (int t = lane; t < 4 * D; t += 64) {         // one lane per (plane, row amount): 4 d entries (more than 64 from d = 17 on)
-                const int sel = t / D, k = t - sel * D;
-                B src;
-#pragma unroll
-                for (int w = 0; w < W; ++w) src.w[w] = sel == 0 ? v.w[w] : (sel == 1 ? pl.w[w] : (sel == 2 ? rv.w[w] : rp.w[w]));
-                const B r = (src.shl(k * D) | src.shr(DD - k * D)) & L::full();
-#pragma unroll
-                for (int w = 0; w < W; ++w) T.rr[sel][k][w] = r.w[w];
-            }
-            for (int c = lane; c < NQ; c += 64) {
-                const int l = c >= DD, bit = c - l * DD;
-                if (l ? e1.get(bit) : e0.get(bit)) {
-                    const int row = bit / D, col = bit - row * D;
-                    const int k = l ? n0 + e1.rank(bit) : e0.rank(bit);
-                    const uint32_t hp = (uint32_t)l | ((uint32_t)row << 8) | ((uint32_t)col << 16);
-                    T.hpos[k] = hp;
-                    if (has_pos) S.posr[(q0 + (uint32_t)k) & PMASK] = hp;
-                }
-            }
+            LatTables<D>& T = PT.t[0];
+            build(T, v, pl, e0, e1, n0, q0, 0u, 0u);
             wave_lds_sync();
-            // ---- one lane per hit, 64 hits per pass: its perspective as two bit-planes, OR-ed into the ring.  d >= 19 (!WHOLE):
-            // after every pass the wave says how far the lattice is (the consumers may take it) and asks for the next pass's
-            // room -- 2d^2 hits x 2d^2 bits are more than the ring holds
+            // one lane per hit, 64 hits per pass.  d >= 19 (!WHOLE): after every pass the wave says how far the lattice is (the
+            // consumers may take it) and asks for the next pass's room -- 2d^2 hits x 2d^2 bits are more than the ring holds
             for (int kb = 0; kb < n; kb += 64) {
                 if (!WHOLE && kb) {
                     lds_publish(S.pq[p], q0 + (uint32_t)kb, lane);
@@ -503,21 +582,13 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                 }
                 const int k = kb + lane;
                 if (k >= n) continue;
-                const uint32_t hp = T.hpos[k];
-                const int layer = (int)(hp & 255u), i = (int)((hp >> 8) & 255u), jj = (int)(hp >> 16);
-                int rs, cs;
-                PS::hit_shifts(layer, i, jj, rs, cs);           // (moving this to the hit-list stage, per qubit lane, was measured: no gain)
-                B a, c, low;
-#pragma unroll
-                for (int w = 0; w < W; ++w) { a.w[w] = T.rr[2 * layer][rs][w]; c.w[w] = T.rr[2 * layer + 1][rs][w]; low.w[w] = T.low[cs][w]; }
-                const B ov = PS::roll_cols_masked(a, cs, low), op = PS::roll_cols_masked(c, cs, low);
-                if (has_stack)
-                    emit_at<D>(bit0 + (uint32_t)k * NQ, ov, op, [&](uint32_t idx, uint32_t val) { atomicOr(&S.bits[idx & BMASK], val); });
+                emit_hit(T, k, q0 + (uint32_t)k);
             }
             wave_lds_sync();                                 // T is rewritten by the next lattice
         }
         if (cnt < 64) break;
     }
+    if (QS > 1) flush();
     lds_publish(S.pq[p], 0xFFFFFFFFu, lane);                 // no lattice left: everything of this wave is in the rings
     stats_out(wave, lane);
 }

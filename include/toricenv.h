@@ -105,6 +105,17 @@ int tq_stack_alloc(int device, uint64_t bytes, void** out);
  * a set-up call, not something to call per step. */
 int tq_stack_free(void* ptr);
 
+/* The stack write runs one persistent workgroup per CU, each with a fixed contiguous share of the stack, dealt to the
+ * XCDs round-robin.  On MI355X the CUs of the odd XCDs store this stream ~20 % slower than those of the even ones (every
+ * box and buffer measured: profiles/r04_workgroup_end_times.txt), so of every pair of workgroups the even one takes
+ * 32 + bias and the odd one 32 - bias of the pair's 64 fine parts -- for d >= 7 and stacks of 64 MB and more (smaller
+ * lattices are bound by the producers, not by the stores: there unequal shares only cost).  Default 5 (or the
+ * environment variable TORICENV_XCD_BIAS, read once); 0 = equal shares; process-wide; changes the speed of
+ * tq_persp_write*, never its result.  EnvSet.pickStackBuffer checks the setting against equal shares on the caller's
+ * own write. */
+int tq_set_xcd_bias(int bias);   /* 0..16, else TQ_E_INVALID */
+int tq_get_xcd_bias(void);
+
 int tq_num_envs(const tq_env* h);
 int tq_size(const tq_env* h);
 

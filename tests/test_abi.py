@@ -64,6 +64,20 @@ def test_errors_are_codes_not_aborts(lib):
         assert rc < 0 and lib.tq_last_error()
 
 
+def test_workgroup_share_setting_is_range_checked(lib):
+    """tq_set_xcd_bias / tq_get_xcd_bias (toricenv.h): a process-wide host setting, 0..16, no device needed."""
+    before = lib.tq_get_xcd_bias()
+    assert 0 <= before <= 16
+    try:
+        for b in (0, 16, 5):
+            assert lib.tq_set_xcd_bias(b) == 0 and lib.tq_get_xcd_bias() == b
+        for b in (-1, 17, 1 << 20):
+            assert lib.tq_set_xcd_bias(b) < 0 and b"xcd bias" in lib.tq_last_error()
+            assert lib.tq_get_xcd_bias() == 5
+    finally:
+        lib.tq_set_xcd_bias(before)
+
+
 def test_python_surface_fails_loudly_without_gpu():
     env = T.make("toric-code-v0", {"size": 5, "min_qubit_errors": 0, "p_error": 0.1})
     assert env.system_size == 5 and int(env.action_space.high[-1]) == 3

@@ -1076,6 +1076,55 @@ def test_scan_after_a_large_stack_leaves_no_stale_cut_points(T):
     gpu.close()
 
 
+@pytest.mark.parametrize("d,n,dtype", [(7, 24576, torch.float32), (9, 8192, torch.bfloat16), (11, 8192, torch.uint8)])
+def test_unequal_workgroup_shares_write_the_same_stack(T, d, n, dtype):
+    """tq_set_xcd_bias: the workgroups of even XCDs take more of the stack than those of odd XCDs (d >= 7, stacks of
+    64 MB and more).  Whatever the shares -- equal, the default, the extreme 48 : 16 -- the stack, the positions and
+    the latch are the same, through the handle's table and through a lattice range (cut points found in the kernel);
+    the equal-share stack is held against the C oracle."""
+    from oracle.c_oracle import CEnvBatch
+    L = T._lib.load()
+    default = L.tq_get_xcd_bias()
+    gpu, _ = make_pair(T, d, n, p=0.12, seed=77, numpy_io=False)
+    try:
+        gpu.resetAll()
+        for _ in range(2):
+            gpu.actorStep(None)
+        st_np = gpu.getStates().cpu().numpy()
+        counts, offsets = gpu.perspectiveCounts()
+        P = int(offsets[-1].item())
+        esize = torch.empty((), dtype=dtype).element_size()
+        assert P * 2 * d * d * esize >= 64 << 20             # large enough for the shares to apply
+        out = {}
+        for bias in (0, default, 16, 3):
+            assert L.tq_set_xcd_bias(bias) == 0 and L.tq_get_xcd_bias() == bias
+            stack = torch.full((P + 8, 2, d, d), 7, dtype=dtype, device=gpu.device)
+            pos = torch.full((P + 8, 3), -1, dtype=torch.int32, device=gpu.device)
+            gpu.writePerspectives(stack, pos, offsets)
+            gpu.check()
+            half = torch.full_like(stack, 7)
+            hpos = torch.full_like(pos, -1)
+            gpu.writePerspectives(half, hpos, offsets, first=0, count=n // 2 + 3)    # a lattice range: no table
+            gpu.check()
+            ph = int(offsets[n // 2 + 3].item())
+            assert torch.equal(half[:ph], stack[:ph]) and torch.equal(hpos[:ph], pos[:ph])
+            assert bool((half[ph:] == 7).all()) and bool((stack[P:] == 7).all()) and bool((pos[P:] == -1).all())
+            out[bias] = (stack, pos)
+        for bias in out:
+            assert torch.equal(out[bias][0], out[0][0]) and torch.equal(out[bias][1], out[0][1]), f"bias {bias} writes another stack"
+        ce = CEnvBatch(d, n, 0.12, seed=77)
+        cper, cpos, ccnt, coff = ce.perspectives(states=st_np, dtype=np.uint8)
+        assert cper.shape[0] == P and np.array_equal(cpos, out[0][1][:P].cpu().numpy())
+        step = 1 << 20
+        for i in range(0, P, step):
+            want = torch.as_tensor(cper[i:i + step], device=gpu.device)
+            assert torch.equal(out[0][0][:P][i:i + step].to(torch.float32), want.to(torch.float32))
+        assert L.tq_set_xcd_bias(17) < 0 and L.tq_set_xcd_bias(-1) < 0 and L.tq_get_xcd_bias() == 3
+    finally:
+        L.tq_set_xcd_bias(default)
+        gpu.close()
+
+
 # ------------------------------------------------------------------ the two-stream loop
 @pytest.mark.parametrize("d,n,chunks", [(7, 16384, 1), (5, 8192, 1), (9, 4096, 4)])
 def test_explore_loop_on_two_streams_equals_the_serial_loop_and_the_oracle(T, d, n, chunks):

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "stream_write.hpp"
+#include "stream_write_runs.hpp"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -75,16 +76,38 @@ struct Timer {
 struct Ctx {
     const uint64_t* vp; int64_t N; const int64_t* off; void* out; int32_t* pos; int64_t P; int* err; const int32_t* split;
     void* ref; int32_t* pref; unsigned long long* bad; double bytes; size_t out_bytes; Timer* t;
+    const int32_t* split_fine; unsigned int* ticket; unsigned launches;      // the scan's table of 1 << STREAM_DYN_LG fine parts; ticket counters, used in turn
+    int bias;                                                                // fine parts (of 32) an odd workgroup hands to its even neighbour
 };
+
+// KIND: 2 = the library's kernel (fine parts from the scan's table, c.bias); 0 = the experiment of tools/stream_write_runs.hpp,
+// runs behind the main runs taken by ticket (schedule SCHED); 1 = the same, one run per workgroup
+template <int D, typename OutT, int NS, int NPW, int NP, int CPW, int RB, int RP, int QS, int KIND, int SCHED, bool STATS>
+void launch_kind(Ctx& c, int grid, const int32_t* sp, unsigned long long* st) {
+    constexpr int WV = NS + NPW + NP;
+    if constexpr (KIND == 2) {
+        hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, STATS, NPW, QS>), dim3(grid), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
+                           (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, sp ? c.split_fine : nullptr, grid == 256 ? 13 : 14, c.bias,
+                           c.ticket + 8 + 2 * (c.launches % 8), c.ticket + 8 + 2 * ((c.launches + 4) % 8), st);
+        ++c.launches;
+    } else if constexpr (KIND == 1) {
+        hipLaunchKernelGGL((tqr::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, STATS, NPW, SCHED>), dim3(grid), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
+                           (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, sp, 8, (unsigned int*)nullptr, (unsigned int*)nullptr, st);
+    } else {
+        unsigned int* tk = c.ticket + c.launches % 8, *tc = c.ticket + (c.launches + 4) % 8;
+        ++c.launches;
+        hipLaunchKernelGGL((tqr::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, STATS, NPW, SCHED>), dim3(grid), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
+                           (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, c.split_fine, tqr::STREAM_DYN_LG, tk, tc, st);
+    }
+}
 
 // GRID: workgroups (a power of two; 256 = one per CU with the scan's cut points, 512 = two per CU -- needs <= 80 KB of LDS --
 // which find their cut points themselves)
-template <int D, typename OutT, int NS, int NPW, int NP, int CPW, int RB, int RP, int GRID = 256, int QS = 1>
+template <int D, typename OutT, int NS, int NPW, int NP, int CPW, int RB, int RP, int GRID = 256, int QS = 1, int KIND = 0, int SCHED = 0>
 void one(Ctx& c, bool stats, bool is_ref) {
     constexpr int WV = NS + NPW + NP;
     const int32_t* sp = GRID == 256 ? c.split : nullptr;
-    auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, false, NPW, QS>), dim3(GRID), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
-                                      (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, sp, (unsigned long long*)nullptr); };
+    auto k = [&] { launch_kind<D, OutT, NS, NPW, NP, CPW, RB, RP, QS, KIND, SCHED, false>(c, GRID, sp, nullptr); };
     CK(hipMemset(c.out, 0x77, c.out_bytes)); CK(hipMemset(c.pos, 0x77, (size_t)c.P * 12));
     k(); CK(hipDeviceSynchronize());
     unsigned long long nb = 0;
@@ -99,16 +122,19 @@ void one(Ctx& c, bool stats, bool is_ref) {
     int e; CK(hipMemcpy(&e, c.err, 4, hipMemcpyDeviceToHost));
     float a = 0, mn = 1e9;
     for (int r = 0; r < 9; ++r) { float x = c.t->run(k); if (r) { a += x; mn = std::min(mn, x); } }
-    printf("  grid %d NS=%d NPW=%d NP=%2d CPW=%2d QS=%d ring 2^%d/2^%d  %7.1f us  %6.0f GB/s (best %6.0f)   %s, latch %d\n", GRID, NS, NPW, NP, CPW, QS, RB, RP, 1e3 * a / 8,
+    printf("  %s grid %d NS=%d NPW=%d NP=%2d CPW=%2d QS=%d %s %d  %7.1f us  %6.0f GB/s (best %6.0f)   %s, latch %d\n",
+           KIND == 0 ? "runs by ticket  " : (KIND == 1 ? "runs, one per wg" : "library kernel  "), GRID, NS, NPW, NP, CPW, QS, KIND == 2 ? "bias" : "sched", KIND == 2 ? c.bias : SCHED, 1e3 * a / 8,
            c.bytes / (a / 8) / 1e6, c.bytes / mn / 1e6, is_ref ? "reference of this sweep" : (nb ? "DIFFERS" : "same bytes"), e);
     if (nb) printf("      %llu differing dwords\n", nb);
     if (!stats || GRID != 256) return;
     unsigned long long* st;
     CK(hipMalloc(&st, sizeof(unsigned long long) * 256 * WV * 4));
     CK(hipMemset(st, 0, sizeof(unsigned long long) * 256 * WV * 4));
-    hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, true, NPW, QS>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off, (OutT*)c.out, c.pos, c.P,
-                       c.err, (int64_t)0, c.N, c.split, st);
-    CK(hipDeviceSynchronize());
+    for (int r = 0; r < 4; ++r) {                            // warm code; the last launch is the one read
+        CK(hipMemset(st, 0, sizeof(unsigned long long) * 256 * WV * 4));
+        launch_kind<D, OutT, NS, NPW, NP, CPW, RB, RP, QS, KIND, SCHED, true>(c, 256, c.split, st);
+        CK(hipDeviceSynchronize());
+    }
     std::vector<unsigned long long> h((size_t)256 * WV * 4);
     CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
     auto agg = [&](int w0, int w1, const char* role, const char* a_name, const char* b_name) {
@@ -116,15 +142,81 @@ void one(Ctx& c, bool stats, bool is_ref) {
         for (int g = 0; g < 256; ++g) for (int w = w0; w < w1; ++w) {
             const unsigned long long* o = &h[((size_t)g * WV + w) * 4];
             if (!o[0]) continue;
-            tot += o[0]; wa += o[1]; wb += o[2]; items += o[3]; mx = std::max(mx, (double)o[0]); ++n;
+            tot += o[0]; wa += o[1]; items += o[3]; mx = std::max(mx, (double)o[0]); ++n;
         }
         if (n) printf("      %-10s waves %5d  alive %9.0f cyc (max %9.0f)  waiting for %s %5.1f %%  %s %5.1f %%  items/wave %7.1f  busy cyc/item %7.0f\n",
                       role, n, tot / n, mx, a_name, 100 * wa / tot, b_name, 100 * wb / tot, items / n, (tot - wa - wb) / std::max(1.0, items));
     };
+    {   // when the workgroups' storers began and ended, on the constant 100 MHz clock: the launch lasts until the LAST one ends
+        uint32_t b0 = 0xFFFFFFFFu; std::vector<double> en(256, 0), bg(256, 1e18);
+        for (int g = 0; g < 256; ++g) for (int w = 0; w < NS; ++w) { const unsigned long long x = h[((size_t)g * WV + w) * 4 + 2]; if (x) b0 = std::min(b0, (uint32_t)(x >> 32)); }
+        for (int g = 0; g < 256; ++g) for (int w = 0; w < NS; ++w) {
+            const unsigned long long x = h[((size_t)g * WV + w) * 4 + 2]; if (!x) continue;
+            bg[g] = std::min(bg[g], (double)((uint32_t)(x >> 32) - b0) / 100.0); en[g] = std::max(en[g], (double)((uint32_t)x - b0) / 100.0);
+        }
+        std::vector<double> se(en); std::sort(se.begin(), se.end());
+        double mean = 0, bmax = 0; for (int g = 0; g < 256; ++g) { mean += en[g] / 256; bmax = std::max(bmax, bg[g]); }
+        printf("      workgroups end (us after the first began): min %.1f  p10 %.1f  median %.1f  mean %.1f  p90 %.1f  max %.1f   last begin %.1f\n",
+               se[0], se[25], se[128], mean, se[230], se[255], bmax);
+        printf("      mean end by XCD (workgroup %% 8):");
+        for (int x = 0; x < 8; ++x) { double m = 0; for (int g = x; g < 256; g += 8) m += en[g] / 32; printf(" %.1f", m); }
+        printf("\n      mean end by position in the stack (32 consecutive workgroups each):");
+        for (int x = 0; x < 8; ++x) { double m = 0; for (int g = 32 * x; g < 32 * x + 32; ++g) m += en[g] / 32; printf(" %.1f", m); }
+        printf("\n");
+    }
     agg(0, NS, "storer", "production", "-");
     agg(NS, NS + NPW, "positions", "production", "-");
     agg(NS + NPW, WV, "producer", "ring room", "commit turn");
     CK(hipFree(st));
+}
+
+// Would a split of the stack that follows the workgroups' OBSERVED rates end the launch sooner?  Pass 0: the scan's equal
+// split, the workgroups' end times from the STATS instantiation; pass k: cut points such that workgroup g gets a share
+// proportional to share_g / end_g of the pass before.  (What a dynamic hand-out of parts would converge to.)
+template <int D, typename OutT, int NS, int NPW, int NP>
+void rebalance(Ctx& c, const std::vector<int64_t>& off_h) {
+    constexpr int WV = NS + NPW + NP;
+    const int64_t N = c.N, P = off_h[N];
+    std::vector<double> share(256, 1.0 / 256);
+    int32_t* sp; CK(hipMalloc(&sp, 4 * 258));
+    unsigned long long* st; CK(hipMalloc(&st, sizeof(unsigned long long) * 256 * WV * 4));
+    for (int pass = 0; pass < 4; ++pass) {
+        std::vector<int32_t> cut(257);
+        double acc = 0;
+        for (int g = 0; g <= 256; ++g) {
+            const int64_t target = g == 256 ? P : (int64_t)(acc * (double)P);
+            cut[g] = (int32_t)(std::lower_bound(off_h.begin(), off_h.begin() + N + 1, target) - off_h.begin());
+            if (g < 256) acc += share[g];
+        }
+        cut[0] = 0; cut[256] = (int32_t)N;
+        CK(hipMemcpy(sp, cut.data(), 4 * 257, hipMemcpyHostToDevice));
+        auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, 8, 14, 12, false, NPW>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
+                                          (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, (const int32_t*)sp, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
+        float a = 0, mn = 1e9;
+        for (int r = 0; r < 9; ++r) { float x = c.t->run(k); if (r) { a += x; mn = std::min(mn, x); } }
+        for (int r = 0; r < 3; ++r) {
+            CK(hipMemset(st, 0, sizeof(unsigned long long) * 256 * WV * 4));
+            hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, 8, 14, 12, true, NPW>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off, (OutT*)c.out, c.pos, c.P,
+                               c.err, (int64_t)0, c.N, (const int32_t*)sp, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, st);
+            CK(hipDeviceSynchronize());
+        }
+        std::vector<unsigned long long> h((size_t)256 * WV * 4);
+        CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+        uint32_t b0 = 0xFFFFFFFFu; std::vector<double> en(256, 0);
+        for (int g = 0; g < 256; ++g) for (int w = 0; w < NS; ++w) { const unsigned long long x = h[((size_t)g * WV + w) * 4 + 2]; if (x) b0 = std::min(b0, (uint32_t)(x >> 32)); }
+        for (int g = 0; g < 256; ++g) for (int w = 0; w < NS; ++w) {
+            const unsigned long long x = h[((size_t)g * WV + w) * 4 + 2]; if (x) en[g] = std::max(en[g], (double)((uint32_t)x - b0) / 100.0);
+        }
+        std::vector<double> se(en); std::sort(se.begin(), se.end());
+        double mean = 0, smin = 1, smax = 0; for (int g = 0; g < 256; ++g) { mean += en[g] / 256; smin = std::min(smin, share[g]); smax = std::max(smax, share[g]); }
+        int e; CK(hipMemcpy(&e, c.err, 4, hipMemcpyDeviceToHost));
+        printf("   pass %d  shares %.3f..%.3f of 1/256   %7.1f us  %6.0f GB/s (best %6.0f)   workgroups end: min %.1f median %.1f mean %.1f max %.1f   latch %d\n", pass,
+               smin * 256, smax * 256, 1e3 * a / 8, c.bytes / (a / 8) / 1e6, c.bytes / mn / 1e6, se[0], se[128], mean, se[255], e);
+        double tot = 0;
+        for (int g = 0; g < 256; ++g) { share[g] = share[g] / std::max(1.0, en[g]); tot += share[g]; }
+        for (int g = 0; g < 256; ++g) share[g] /= tot;
+    }
+    CK(hipFree(st)); CK(hipFree(sp));
 }
 
 template <int D, typename OutT>
@@ -153,7 +245,15 @@ int run(int64_t N, double q, const char* tname) {
     const size_t out_bytes = ((size_t)P * NQ * ES + 4095) & ~(size_t)4095;
     printf("d=%d %s  lattices %lld  perspectives %lld (%.1f per lattice)  algorithmic bytes %.4f GB\n", D, tname, (long long)N, (long long)P, (double)P / N, bytes / 1e9);
     Timer t;
-    Ctx c{vp, N, off, nullptr, nullptr, P, err, split, nullptr, nullptr, nullptr, bytes, out_bytes, &t};
+    Ctx c{vp, N, off, nullptr, nullptr, P, err, split, nullptr, nullptr, nullptr, bytes, out_bytes, &t, nullptr, nullptr, 0u, 0};
+    {   // the table the library's scan writes: 1 << STREAM_DYN_LG fine parts; eight ticket counters
+        int32_t* sf; CK(hipMalloc(&sf, 4 * ((1 << tqr::STREAM_DYN_LG) + 4)));
+        hipLaunchKernelGGL(tq::k_scan_final, dim3((unsigned)((N + tq::SCAN_CHUNK - 1) / tq::SCAN_CHUNK)), dim3(256), 0, 0, counts,
+                           (const int64_t*)part, off, (int32_t*)nullptr, N, sf, tqr::STREAM_DYN_LG);
+        CK(hipDeviceSynchronize());
+        c.split_fine = sf;
+        CK(hipMalloc(&c.ticket, 96)); CK(hipMemset(c.ticket, 0, 96));   // 8 ticket counters (runs experiment) + 8 pairs of slot counters
+    }
     CK(hipMalloc(&c.ref, out_bytes)); CK(hipMalloc(&c.pref, (size_t)P * 12 + 4096)); CK(hipMalloc(&c.pos, (size_t)P * 12 + 4096)); CK(hipMalloc(&c.bad, 8));
     // candidate buffers: the product configuration on each, the fastest is used for the sweep
     constexpr int NS0 = D <= 5 ? 2 : 4, NP0 = D <= 5 ? 13 : (D >= 13 ? 7 : 11);
@@ -169,15 +269,52 @@ int run(int64_t N, double q, const char* tname) {
     for (int b = 0; b < 8; ++b) {
         void* ob = bufs[b];
         auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS0, NP0, 8, 14, 12>), dim3(256), dim3(64 * (NS0 + 1 + NP0)), 0, 0, vp, N, off, (OutT*)ob, c.pos, P, err,
-                                          (int64_t)0, N, (const int32_t*)split, (unsigned long long*)nullptr); };
+                                          (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
         float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(k); if (r) a += x; }
         printf(" %s %.0f", b < 2 ? "hipMalloc" : "vmm", bytes / (a / 5) / 1e6);
         if (a < best_ms) { best_ms = a; best = b; }
     }
     printf("  -> buffer %d\n", best);
     c.out = bufs[best];
-#define CFG(NS, NPW, NP, CPW, STATS, REF) one<D, OutT, NS, NPW, NP, CPW, 14, 12>(c, STATS, REF);
-#define CFQ(NS, NPW, NP, QS, STATS, REF) one<D, OutT, NS, NPW, NP, 8, 14, 12, 256, QS>(c, STATS, REF);
+    if (getenv("TUNE_BIAS")) {                                // unequal fixed shares for even / odd XCDs, on every buffer
+        constexpr int NPW0 = (ES < 4 && D >= 5) ? 2 : 1, NSP = D == 5 && ES == 2 ? 3 : NS0, NPP = D >= 17 ? 3 : (D >= 13 ? 8 - NPW0 : 16 - NSP - NPW0);
+        const bool st = getenv("TUNE_STATS") != nullptr;
+        for (int b = 0; b < 8; ++b) {
+            printf(" buffer %d\n", b); c.out = bufs[b];
+            const int biases[] = {0, 2, 3, 4, 5, 6, 0};
+            for (int i = 0; i < 7; ++i) { c.bias = biases[i]; one<D, OutT, NSP, NPW0, NPP, 8, 14, 12, 256, 1, 2, 0>(c, st && (i == 0 || i == 2 || i == 3), i == 0); }
+            c.bias = 0;
+        }
+        return 0;
+    }
+    if (getenv("TUNE_RUNS")) {                                // the runs experiment against the library's kernel, on every buffer
+        constexpr int NPW0 = (ES < 4 && D >= 5) ? 2 : 1, NSP = D == 5 && ES == 2 ? 3 : NS0, NPP = D >= 17 ? 3 : (D >= 13 ? 8 - NPW0 : 16 - NSP - NPW0);
+        const bool st = getenv("TUNE_STATS") != nullptr;
+        for (int b = 0; b < 8; ++b) {
+            printf(" buffer %d\n", b); c.out = bufs[b];
+            one<D, OutT, NSP, NPW0, NPP, 8, 14, 12, 256, 1, 2, 0>(c, st, true);
+            one<D, OutT, NSP, NPW0, NPP, 8, 14, 12, 256, 1, 1, 0>(c, false, false);
+            one<D, OutT, NSP, NPW0, NPP, 8, 14, 12, 256, 1, 0, 0>(c, st, false);
+            one<D, OutT, NSP, NPW0, NPP, 8, 14, 12, 256, 1, 0, 1>(c, false, false);
+            one<D, OutT, NSP, NPW0, NPP, 8, 14, 12, 256, 1, 0, 4>(c, st, false);
+            one<D, OutT, NSP, NPW0, NPP, 8, 14, 12, 256, 1, 2, 0>(c, false, false);
+        }
+        return 0;
+    }
+    if (getenv("TUNE_REBALANCE")) {
+        constexpr int NPW0 = (ES < 4 && D >= 5) ? 2 : 1, NSP = D == 5 && ES == 2 ? 3 : NS0, NPP = D >= 17 ? 3 : (D >= 13 ? 8 - NPW0 : 16 - NSP - NPW0);
+        std::vector<int64_t> off_h((size_t)N + 1);
+        CK(hipMemcpy(off_h.data(), off, 8 * (N + 1), hipMemcpyDeviceToHost));
+        for (int b = 0; b < 8; ++b) { printf(" buffer %d\n", b); c.out = bufs[b]; rebalance<D, OutT, NSP, NPW0, NPP>(c, off_h); }
+        return 0;
+    }
+    if (getenv("TUNE_SPREAD")) {                              // the product configuration on EVERY candidate buffer, with the workgroups' end times
+        constexpr int NPW0 = (ES < 4 && D >= 5) ? 2 : 1, NSP = D == 5 && ES == 2 ? 3 : NS0, NPP = D >= 17 ? 3 : (D >= 13 ? 8 - NPW0 : 16 - NSP - NPW0);
+        for (int b = 0; b < 8; ++b) { printf(" buffer %d\n", b); c.out = bufs[b]; one<D, OutT, NSP, NPW0, NPP, 8, 14, 12, 256, 1, 2, 0>(c, true, b == 0); }
+        return 0;
+    }
+#define CFG(NS, NPW, NP, CPW, STATS, REF) one<D, OutT, NS, NPW, NP, CPW, 14, 12, 256, 1, 0, 0>(c, STATS, REF);
+#define CFQ(NS, NPW, NP, QS, STATS, REF) one<D, OutT, NS, NPW, NP, 8, 14, 12, 256, QS, 2, 0>(c, STATS, REF);
     if constexpr (D == 3) {
         CFQ(2, 1, 13, 1, true, true)
         CFQ(2, 1, 13, 8, true, false)
@@ -252,9 +389,9 @@ int run_all(int64_t N, double q) {
         void* ob;
         if (b < 2) CK(hipMalloc(&ob, out_bytes + (size_t)b * (3u << 20)));
         else ob = alloc_vmm(out_bytes + (size_t)b * (2u << 20));
-        auto kf = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS0, NP1, 8, 14, 12, false, 1>), dim3(256), dim3(64 * (NS0 + 1 + NP1)), 0, 0, vp, N, off, (float*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, (unsigned long long*)nullptr); };
-        auto kb = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, tq::bf16_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (tq::bf16_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, (unsigned long long*)nullptr); };
-        auto ku = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, uint8_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (uint8_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, (unsigned long long*)nullptr); };
+        auto kf = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS0, NP1, 8, 14, 12, false, 1>), dim3(256), dim3(64 * (NS0 + 1 + NP1)), 0, 0, vp, N, off, (float*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
+        auto kb = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, tq::bf16_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (tq::bf16_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
+        auto ku = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, uint8_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (uint8_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
         auto km4 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 4, 0); };
         auto km2 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 2, 0); };
         auto km1 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ, 0); };

@@ -27,6 +27,8 @@ SYMBOLS = [
     ("tq_set_perror_schedule", _i, [_vp, _i, _d, _d, _d]),
     ("tq_stack_alloc", _i, [_i, _u64, C.POINTER(_vp)]),
     ("tq_stack_free", _i, [_vp]),
+    ("tq_set_xcd_bias", _i, [_i]),
+    ("tq_get_xcd_bias", _i, []),
     ("tq_num_envs", _i, [_vp]),
     ("tq_size", _i, [_vp]),
     ("tq_reset_all", _i, [_vp, _vp, _vp]),

@@ -696,9 +696,9 @@ __global__ __launch_bounds__(256) void k_scan_final(const int32_t* __restrict__ 
             // cut points with T_k = 0 (k = 0, and k < G / total when the stack has fewer perspectives than parts) lie in
             // no thread's interval (o[0], o[8]]: lattice 0 is their answer.  Every entry of the table is written by
             // every scan -- nothing of an earlier, larger stack survives in it.
-            if (blockIdx.x == 0 && tid == 0) {
+            if (blockIdx.x == 0) {
                 const int64_t kz = kfloor(0);
-                for (int64_t k = 0; k <= kz; ++k) split[k] = 0;
+                for (int64_t k = tid; k <= kz; k += 256) split[k] = 0;
             }
             if (o[8] > o[0]) {
                 const int64_t kA = kfloor(o[0]) + 1, kB = kfloor(o[8]);

@@ -1,7 +1,7 @@
 // Perspective stack write, producer / storer form (gfx950 / CDNA4).
 //
-// One persistent workgroup per CU owns a CONTIGUOUS range of the output (lattices [e_lo, e_hi), cut so
-// that every workgroup gets the same number of perspectives, k_scan_final / k_split).  Inside the workgroup
+// One persistent workgroup per CU owns a CONTIGUOUS range of the output (lattices [e_lo, e_hi), cut by perspective
+// count, k_scan_final / find_cut: one fixed share per workgroup, larger for the workgroups on the faster XCDs).  Inside the workgroup
 // the two jobs of the stack write are done by different waves:
 //   * NP producer waves build lattice bitstreams (lattice.hpp, PStream: rotated planes by ballot, table of
 //     row-rolled planes, one lane per hit, ds_or_b32) -- not into a per-wave buffer but into ONE ring in LDS
@@ -129,8 +129,10 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offse
     if (lane == 0) split[k] = (int32_t)e;
 }
 
-// STATS (diagnostic builds only, tools/stream_bench.hip): every wave leaves {cycles alive, cycles waiting (A), cycles
-// waiting (B), items} in stats[(block * waves + wave) * 4 ..]; A/B = storers: production / -, producers: ring room / - (until round 3: commit turn).
+// STATS (diagnostic builds only, tools/stream_tune.hip): every wave leaves {cycles alive, cycles waiting, begin << 32 | end on
+// the 100 MHz clock, items} in stats[(block * waves + wave) * 4 ..]; waiting = storers: for production, producers: for ring room.
+// split / lg / bias / slots: see "this workgroup's range" below; slots_clear = the slot counters of a LATER launch, zeroed here
+// (the host goes round a few pairs of counters: a launch never finds its own dirty, whatever became of the one before)
 // NPW: positions waves (chunks of 1 KiB dealt round-robin among them)
 // QS: lattices whose tables a producer keeps alive (1 = one lattice at a time; > 1 = hit queue across lattices, d <= 7)
 template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false, int NPW = 1, int QS = 1>
@@ -138,16 +140,18 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                                                                   const int64_t* __restrict__ offsets, OutT* __restrict__ out,
                                                                   int32_t* __restrict__ pos, int64_t capacity,
                                                                   int* __restrict__ err, int64_t e_begin, int64_t e_end,
-                                                                  const int32_t* __restrict__ split,
+                                                                  const int32_t* __restrict__ split, int lg, int bias,
+                                                                  unsigned int* __restrict__ slots, unsigned int* __restrict__ slots_clear,
                                                                   unsigned long long* __restrict__ stats = nullptr) {
     using L = Lat<D>;
     using PS = PStream<D>;
-    unsigned long long t_begin = 0, t_a = 0, t_b = 0, n_items = 0;
-    if (STATS) t_begin = __builtin_readcyclecounter();
+    unsigned long long t_begin = 0, t_a = 0, t_rt = 0, n_items = 0;
+    if (STATS) { t_begin = __builtin_readcyclecounter(); t_rt = __builtin_amdgcn_s_memrealtime(); }
     auto stats_out = [&](int wv, int ln) {
-        if (STATS && ln == 0) {
+        if (STATS && ln == 0) {                              // o[2]: the wave's life on the constant 100 MHz clock, begin << 32 | end
             unsigned long long* o = stats + ((size_t)blockIdx.x * (NS + NPW + NP) + wv) * 4;
-            o[0] = __builtin_readcyclecounter() - t_begin; o[1] = t_a; o[2] = t_b; o[3] = n_items;
+            o[0] = __builtin_readcyclecounter() - t_begin; o[1] = t_a;
+            o[2] = (t_rt << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull); o[3] = n_items;
         }
     };
     using Enc = OutEnc<OutT>;
@@ -173,15 +177,51 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
-    // ---- this workgroup's range (wave-uniform): from the scan's table, or -- split == nullptr: a lattice sub-range, or
-    // offsets that did not come with the scan -- found here by waves 0 and 1 (gridDim.x must be a power of two)
+    // ---- this workgroup's range (wave-uniform).  The stack is cut into 1 << lg FINE parts of equal perspective count, RR of
+    // them per workgroup on average (a power of two): cut points from the scan's table `split` (k_scan_final), or --
+    // split == nullptr: a lattice sub-range, or offsets that did not come with the scan -- found here by waves 0 and 1.
+    // The shares are NOT equal: the CUs of the odd XCDs of an MI355X store this stream ~20 % slower than those of the even
+    // ones -- with equal shares the even XCDs' workgroups end at 0.80 of the launch, on every box and buffer measured
+    // (profiles/r04_workgroup_end_times.txt).  So every pair of shares (2 RR fine parts) is cut into a LARGE slot of
+    // RR + bias and a SMALL one of RR - bias, and a workgroup takes the next free large slot if it runs on an even XCD
+    // (HW_REG_XCC_ID), the next free small one otherwise: two counters, one atomic per workgroup.  Workgroups go to the
+    // XCDs round-robin, but from where the dispatcher happens to stand (other streams' kernels move it:
+    // tools/xcc_id_probe.hip), so blockIdx.x says nothing about the XCD; and whatever the dispatcher does, gridDim.x
+    // workgroups take gridDim.x different slots -- if one kind runs out the other kind is taken.
+    // Equal shares (bias = 0, slot = blockIdx.x) where the launch is not bound by the stores: small stacks, and the host
+    // passes bias = 0 for d <= 5, whose launches are bound by the producers (d=5: 108 -> 121 us with 5 / 32,
+    // profiles/r04_xcd_bias_sweep.txt).
+    const int RR = (1 << lg) / (int)gridDim.x;
+    if (!slots || (offsets[e_end] - offsets[e_begin]) * (int64_t)(NQ * sizeof(OutT)) < (int64_t)(64 << 20) || bias >= RR) bias = 0;
+    __shared__ int slot_s[2];
+    if (threadIdx.x == 0) {
+        int large = !(blockIdx.x & 1), idx = (int)(blockIdx.x >> 1);
+        if (bias > 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            large = !(xcc & 1u);
+            const unsigned half = gridDim.x >> 1;
+            unsigned t = atomicAdd(&slots[large], 1u);
+            if (t >= half) { large ^= 1; t = atomicAdd(&slots[large], 1u); }
+            idx = t < half ? (int)t : -1;                     // (-1: the counters were not zero when the launch began)
+        }
+        slot_s[0] = large; slot_s[1] = idx;
+        if (blockIdx.x == 0 && slots_clear) { slots_clear[0] = 0u; slots_clear[1] = 0u; }
+    }
+    __syncthreads();
+    if (slot_s[1] < 0) {
+        if (threadIdx.x == 0) atomicOr(err, ERR_INTERNAL);
+        return;
+    }
+    const int f_lo = slot_s[1] * 2 * RR + (slot_s[0] ? 0 : RR + bias);
+    const int f_hi = f_lo + (slot_s[0] ? RR + bias : RR - bias);
     int64_t e_lo, e_hi;
     if (split) {
-        e_lo = split[blockIdx.x]; e_hi = split[blockIdx.x + 1];
+        e_lo = split[f_lo]; e_hi = split[f_hi];
     } else {
         __shared__ int64_t cut[2];
         if (wave < 2) {
-            const int64_t e = find_cut(offsets, e_begin, e_end, (int)blockIdx.x + wave, 31 - __clz((int)gridDim.x), lane);
+            const int64_t e = find_cut(offsets, e_begin, e_end, wave ? f_hi : f_lo, lg, lane);
             if (lane == 0) cut[wave] = e;
         }
         __syncthreads();

@@ -420,7 +420,8 @@ class EnvSet:
         self._positions = positions
 
     def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=10,
-                        kinds=("torch", "chunked"), park=False, first=0, count=None, timer=None, passes=2, among=None):
+                        kinds=("torch", "chunked"), park=False, first=0, count=None, timer=None, passes=2, among=None,
+                        check_shares=True):
         """Set-up helper: allocate ``candidates`` stack buffers (``capacity`` perspectives each, default the worst
         case no_envs * 2*d*d), time the stack write on each of them and keep the fastest.  On MI355X the rate of a
         write stream into a buffer depends on the buffer AND on the stream's shape (5.2-6.9 TB/s for this kernel,
@@ -439,7 +440,9 @@ class EnvSet:
         -- the driver wipes freed device memory in the background, tens of GB of it take HBM bandwidth away from
         whatever runs in the next tens of milliseconds (a benchmark's timed region, say).
         ``first`` / ``count``: the default timer writes that lattice range only (a consumer that walks the batch in ranges
-        with a small buffer: ``capacity`` is then the small buffer's).  Synchronises; never call it in the step loop."""
+        with a small buffer: ``capacity`` is then the small buffer's).  ``check_shares``: also time the kept buffer with
+        equal shares per workgroup against the library's unequal ones (toricenv.h: tq_set_xcd_bias) and keep the faster
+        setting (report["xcd_bias"]).  Synchronises; never call it in the step loop."""
         d, nq = self.size, 2 * self.size * self.size
         cap = self.no_envs * nq if capacity is None else int(capacity)
         if positions is None:
@@ -502,6 +505,24 @@ class EnvSet:
         report = {"candidates": len(ms), "candidates_asked": int(candidates) if among is None else len(ms), "write_ms": ms, "write_ms_min": [float(min(x)) for x in samples], "chosen": chosen,
                   "probe_ms_chosen": ms[chosen], "writes_per_candidate": len(samples[0]), "kinds": used,
                   "addresses": [hex(x.data_ptr()) for x in keep]}
+        # The shares of the write's workgroups (tq_set_xcd_bias: the even XCDs' workgroups take more of the stack) against
+        # equal shares, on the buffer that was kept: the setting rests on a measured asymmetry of MI355X, so it is checked
+        # where it is used.  Process-wide; d <= 5 never uses it.
+        if check_shares and d >= 7:
+            L = self._L
+            b0 = int(L.tq_get_xcd_bias())
+            if b0 > 0:
+                L.tq_set_xcd_bias(0)
+                eq = float(np.median(list(timer(best, per_pass)) + list(timer(best, per_pass))))
+                L.tq_set_xcd_bias(b0)
+                un = float(np.median(list(timer(best, per_pass)) + list(timer(best, per_pass))))
+                keep_bias = un <= eq
+                if not keep_bias:
+                    L.tq_set_xcd_bias(0)
+                report["xcd_bias"] = {"bias": b0 if keep_bias else 0, "write_ms_biased": un, "write_ms_equal_shares": eq}
+                report["probe_ms_chosen"] = min(un, eq)
+            else:
+                report["xcd_bias"] = {"bias": 0}
         del keep, rejected
         if not park:
             torch.cuda.empty_cache()

@@ -34,7 +34,7 @@ rank 0's HBM is measured right after and reported beside it (`hbm_ring`); `ranks
 Prints ONE JSON line on rank 0 (contract in the task statement).  Every leg -- the headline, `configs4_shard_on_one_gpu`,
 `bf16_stack`, `configs3_on_one_gpu.{one_shot,chunks_4}` -- carries `stack_buffer_probe`, `stack_verified` (the timed buffer
 holds the right bytes; a failure voids the line) and its own `roofline` (HIP events on the write's stream around every
---event-every-th write; `probe_ms_chosen`, `timed_write_ms`, `timed_over_probe`, `default_buffer`); `cpu_baseline` (the
+--event-every-th write; `probe_ms_chosen`, `timed_write_ms`, `timed_over_probe`, `default_buffer`, `workgroup_shares` = the XCD bias in force and the probe's biased-against-equal timing); `cpu_baseline` (the
 oracle's ports on the host cores, rank 0, N=1 only) and `nn_in_loop` (configs[2] as written: the stack fed to NN_11 and
 device-side selection in the loop; N=1 only, --nn-steps 0 to skip).  --shards > 1, --graph and --policy nn11 take the
 serial path (run_serial).

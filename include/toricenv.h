@@ -149,8 +149,9 @@ int tq_is_terminal(tq_env* h, uint8_t* out, void* stream);
 
 /* generatePerspectiveBatch, step 1 (numba/util_actor.py:56-67 + cumsum :35): counts i32[N]
  * (may be NULL) and offsets i64[N+1] (exclusive scan, offsets[N] = P).  A by-product are the cut points of the batch
- * into 256 parts of equal perspective count that tq_persp_write(the same `offsets` pointer) uses; the handle keeps the
- * tables of the last TWO calls (a write that is still running on another stream reads the older one). */
+ * into 8192 fine parts of equal perspective count from which tq_persp_write(the same `offsets` pointer) makes its 256
+ * workgroups' shares; the handle keeps the tables of the last TWO calls (a write that is still running on another stream
+ * reads the older one). */
 int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream);
 /* generatePerspectiveBatch + np.concatenate, step 2 (numba/util_actor.py:33-39): writes the
  * env-major stack out[P,2,d,d] of element type `dtype` and positions i32[P,3] (may be NULL)
@@ -159,7 +160,9 @@ int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream);
  * `offsets` must be the scan of the lattices' CURRENT perspective counts (tq_persp_count after the last call that
  * changed a syndrome).  The device checks it: offsets that are not (stale, shifted, all zero, decreasing, from another
  * batch) are refused -- the kernel stores nothing outside [0, min(offsets[N], capacity)) perspectives, every wait in
- * it is bounded, the grid drains, and TQ_E_INVALID is latched for tq_check; the handle stays usable. */
+ * it is bounded, the grid drains, and TQ_E_INVALID is latched for tq_check; the handle stays usable.
+ * At most FOUR stack writes of one handle may be in flight at a time (on whatever streams): their workgroups take their
+ * shares from a ring of eight counter pairs, and every write zeroes the pair four writes ahead (tq_set_xcd_bias). */
 int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positions,
                    int64_t capacity, int dtype, void* stream);
 /* The same for the lattices [first, first + count) only: `out` / `positions` receive the perspectives

@@ -331,6 +331,10 @@ class ExploreLeg:
         # timed region that follow.
         for _ in range(SETTLE):
             self.loop.step()
+        # ... and the probe's figure for the kept buffer is taken again HERE, in the loop's own regime: the candidates were
+        # timed in bursts between allocations and other candidates' writes, 2-4 % slower than the same write a moment later
+        self.probe["probe_ms_in_bursts"] = self.probe["probe_ms_chosen"]
+        self.probe["probe_ms_chosen"] = float(np.median(self.loop.time_writes(self.stack, 8, skip=1)))
         self.loop.drain()
         torch.cuda.synchronize(self.device)
         self.probe["settle_steps"] = SETTLE

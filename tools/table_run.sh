@@ -15,3 +15,7 @@ run d7_bf16 --out-dtype bf16
 run d7_u8 --out-dtype u8
 run d5 --size 5
 run d3 --size 3
+run d17 --size 17 --p-error 0.08 --envs 8192
+run d19 --size 19 --p-error 0.07 --envs 8192
+run d21 --size 21 --p-error 0.06 --envs 8192
+python3 tools/table_summary.py "$OUT" | tee "$OUT/summary.txt"

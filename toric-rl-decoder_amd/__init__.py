@@ -7,7 +7,8 @@ Import it as ``toric_rl_decoder_amd`` (the directory name has a hyphen).
 """
 from ._lib import ToricEnvError, build, load, LIB_PATH  # noqa: F401
 from .envset import (EnvSet, ToricEnv, TransitionBlock, alloc_stack, alloc_chunked, generatePerspectiveBatch,  # noqa: F401
-                     generateTransitionParallel, make, to_structured, transition_dtype, SUPPORTED_SIZES)
+                     generateTransitionParallel, make, to_structured, transition_dtype, SUPPORTED_SIZES,
+                     configured_xcd_bias, set_xcd_bias)
 
 from .policy import (NN_11, evaluate, predictMaxOptimized, seed_select, segment_max, selectActionBatch,  # noqa: F401,E402
                      selectActionEnvSet, _selectActionBatch_prime, prediction_smart,

@@ -228,6 +228,25 @@ def to_structured(unpacked, size):
     return rec
 
 
+_CONFIGURED_XCD_BIAS = None
+
+
+def configured_xcd_bias():
+    """The workgroup-share setting this process was started with (toricenv.h: tq_set_xcd_bias; the library's default or
+    TORICENV_XCD_BIAS), whatever pickStackBuffer's checks have left in force since."""
+    global _CONFIGURED_XCD_BIAS
+    if _CONFIGURED_XCD_BIAS is None:
+        _CONFIGURED_XCD_BIAS = int(_lib.load().tq_get_xcd_bias())
+    return _CONFIGURED_XCD_BIAS
+
+
+def set_xcd_bias(bias):
+    """tq_set_xcd_bias for this process, remembered as the configured value (pickStackBuffer checks THAT against equal shares)."""
+    global _CONFIGURED_XCD_BIAS
+    check(_lib.load().tq_set_xcd_bias(int(bias)))
+    _CONFIGURED_XCD_BIAS = int(bias)
+
+
 class EnvSet:
     """Batch of N toric-code lattices resident on one MI355X (reference: src/EnvSet.py:4-51).
 
@@ -250,6 +269,7 @@ class EnvSet:
         self.terminal_reward = float(getattr(env, "terminal_reward", 100.0))
         self.max_steps_per_episode = int(max_steps_per_episode)
         self._L = _lib.load()
+        configured_xcd_bias()                                    # (recorded before any probe of this process changes it)
         with torch.cuda.device(self.device):
             check(self._L.tq_create(C.byref(self._h), self.no_envs, self.size, self.device.index,
                                     C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), self.first_env_id))
@@ -510,7 +530,7 @@ class EnvSet:
         # where it is used.  Process-wide; d <= 5 never uses it.
         if check_shares and d >= 7:
             L = self._L
-            b0 = int(L.tq_get_xcd_bias())
+            b0 = configured_xcd_bias()                          # not tq_get_xcd_bias(): an earlier probe of this process may have switched it off
             if b0 > 0:
                 L.tq_set_xcd_bias(0)
                 eq = float(np.median(list(timer(best, per_pass)) + list(timer(best, per_pass))))

@@ -161,8 +161,8 @@ int tq_persp_count(tq_env* h, int32_t* counts, int64_t* offsets, void* stream);
  * changed a syndrome).  The device checks it: offsets that are not (stale, shifted, all zero, decreasing, from another
  * batch) are refused -- the kernel stores nothing outside [0, min(offsets[N], capacity)) perspectives, every wait in
  * it is bounded, the grid drains, and TQ_E_INVALID is latched for tq_check; the handle stays usable.
- * At most FOUR stack writes of one handle may be in flight at a time (on whatever streams): their workgroups take their
- * shares from a ring of eight counter pairs, and every write zeroes the pair four writes ahead (tq_set_xcd_bias). */
+ * At most EIGHT stack writes of one handle may be in flight at a time (on whatever streams): their workgroups take their
+ * shares through a ring of eight counter sets (tq_set_xcd_bias); a write captured into a HIP graph may be replayed. */
 int tq_persp_write(tq_env* h, const int64_t* offsets, void* out, int32_t* positions,
                    int64_t capacity, int dtype, void* stream);
 /* The same for the lattices [first, first + count) only: `out` / `positions` receive the perspectives

@@ -1125,6 +1125,45 @@ def test_unequal_workgroup_shares_write_the_same_stack(T, d, n, dtype):
         gpu.close()
 
 
+def test_stack_write_in_a_replayed_graph_takes_its_shares_again(T):
+    """A stack write large enough for the unequal shares, captured into a HIP graph (three writes: not the number of
+    counter sets the handle goes round) and replayed: every replay finds the slot counters of the captured launches as the
+    launch before left them -- zero -- and writes the whole stack again."""
+    d, n = 7, 24576
+    gpu, _ = make_pair(T, d, n, p=0.12, seed=31, numpy_io=False)
+    try:
+        gpu.resetAll()
+        gpu.actorStep(None)
+        counts, offsets = gpu.perspectiveCounts()
+        P = int(offsets[-1].item())
+        assert P * 2 * d * d * 4 >= 64 << 20 and T._lib.load().tq_get_xcd_bias() > 0
+        ref = torch.empty((P, 2, d, d), dtype=torch.float32, device=gpu.device)
+        rpos = torch.empty((P, 3), dtype=torch.int32, device=gpu.device)
+        gpu.writePerspectives(ref, rpos, offsets)
+        gpu.check()
+        bufs = [torch.zeros_like(ref) for _ in range(3)]
+        poss = [torch.zeros_like(rpos) for _ in range(3)]
+        torch.cuda.synchronize(gpu.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for b, q in zip(bufs, poss):
+                gpu.writePerspectives(b, q, offsets)
+        for replay in range(4):
+            for b, q in zip(bufs, poss):
+                b.zero_()
+                q.zero_()
+            g.replay()
+            torch.cuda.synchronize(gpu.device)
+            gpu.check()
+            for b, q in zip(bufs, poss):
+                assert torch.equal(b, ref) and torch.equal(q, rpos), f"replay {replay} wrote another stack"
+        gpu.writePerspectives(bufs[0], poss[0], offsets)         # and eagerly afterwards
+        gpu.check()
+        assert torch.equal(bufs[0], ref)
+    finally:
+        gpu.close()
+
+
 # ------------------------------------------------------------------ the two-stream loop
 @pytest.mark.parametrize("d,n,chunks", [(7, 16384, 1), (5, 8192, 1), (9, 4096, 4)])
 def test_explore_loop_on_two_streams_equals_the_serial_loop_and_the_oracle(T, d, n, chunks):

@@ -88,7 +88,7 @@ void launch_kind(Ctx& c, int grid, const int32_t* sp, unsigned long long* st) {
     if constexpr (KIND == 2) {
         hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, STATS, NPW, QS>), dim3(grid), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
                            (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, sp ? c.split_fine : nullptr, grid == 256 ? 13 : 14, c.bias,
-                           c.ticket + 8 + 2 * (c.launches % 8), c.ticket + 8 + 2 * ((c.launches + 4) % 8), st);
+                           c.ticket + 8 + 4 * (c.launches % 8), st);
         ++c.launches;
     } else if constexpr (KIND == 1) {
         hipLaunchKernelGGL((tqr::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, STATS, NPW, SCHED>), dim3(grid), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
@@ -191,13 +191,13 @@ void rebalance(Ctx& c, const std::vector<int64_t>& off_h) {
         cut[0] = 0; cut[256] = (int32_t)N;
         CK(hipMemcpy(sp, cut.data(), 4 * 257, hipMemcpyHostToDevice));
         auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, 8, 14, 12, false, NPW>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
-                                          (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, (const int32_t*)sp, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
+                                          (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, (const int32_t*)sp, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
         float a = 0, mn = 1e9;
         for (int r = 0; r < 9; ++r) { float x = c.t->run(k); if (r) { a += x; mn = std::min(mn, x); } }
         for (int r = 0; r < 3; ++r) {
             CK(hipMemset(st, 0, sizeof(unsigned long long) * 256 * WV * 4));
             hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, 8, 14, 12, true, NPW>), dim3(256), dim3(64 * WV), 0, 0, c.vp, c.N, c.off, (OutT*)c.out, c.pos, c.P,
-                               c.err, (int64_t)0, c.N, (const int32_t*)sp, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, st);
+                               c.err, (int64_t)0, c.N, (const int32_t*)sp, 8, 0, (unsigned int*)nullptr, st);
             CK(hipDeviceSynchronize());
         }
         std::vector<unsigned long long> h((size_t)256 * WV * 4);
@@ -252,7 +252,7 @@ int run(int64_t N, double q, const char* tname) {
                            (const int64_t*)part, off, (int32_t*)nullptr, N, sf, tqr::STREAM_DYN_LG);
         CK(hipDeviceSynchronize());
         c.split_fine = sf;
-        CK(hipMalloc(&c.ticket, 96)); CK(hipMemset(c.ticket, 0, 96));   // 8 ticket counters (runs experiment) + 8 pairs of slot counters
+        CK(hipMalloc(&c.ticket, 160)); CK(hipMemset(c.ticket, 0, 160));   // 8 ticket counters (runs experiment) + 8 sets of 4 slot counters
     }
     CK(hipMalloc(&c.ref, out_bytes)); CK(hipMalloc(&c.pref, (size_t)P * 12 + 4096)); CK(hipMalloc(&c.pos, (size_t)P * 12 + 4096)); CK(hipMalloc(&c.bad, 8));
     // candidate buffers: the product configuration on each, the fastest is used for the sweep
@@ -269,7 +269,7 @@ int run(int64_t N, double q, const char* tname) {
     for (int b = 0; b < 8; ++b) {
         void* ob = bufs[b];
         auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS0, NP0, 8, 14, 12>), dim3(256), dim3(64 * (NS0 + 1 + NP0)), 0, 0, vp, N, off, (OutT*)ob, c.pos, P, err,
-                                          (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
+                                          (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
         float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(k); if (r) a += x; }
         printf(" %s %.0f", b < 2 ? "hipMalloc" : "vmm", bytes / (a / 5) / 1e6);
         if (a < best_ms) { best_ms = a; best = b; }
@@ -389,9 +389,9 @@ int run_all(int64_t N, double q) {
         void* ob;
         if (b < 2) CK(hipMalloc(&ob, out_bytes + (size_t)b * (3u << 20)));
         else ob = alloc_vmm(out_bytes + (size_t)b * (2u << 20));
-        auto kf = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS0, NP1, 8, 14, 12, false, 1>), dim3(256), dim3(64 * (NS0 + 1 + NP1)), 0, 0, vp, N, off, (float*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
-        auto kb = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, tq::bf16_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (tq::bf16_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
-        auto ku = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, uint8_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (uint8_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
+        auto kf = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS0, NP1, 8, 14, 12, false, 1>), dim3(256), dim3(64 * (NS0 + 1 + NP1)), 0, 0, vp, N, off, (float*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
+        auto kb = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, tq::bf16_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (tq::bf16_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
+        auto ku = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, uint8_t, NS0, NP2, 8, 14, 12, false, 2>), dim3(256), dim3(64 * (NS0 + 2 + NP2)), 0, 0, vp, N, off, (uint8_t*)ob, pos, P, err, (int64_t)0, N, (const int32_t*)split, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
         auto km4 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 4, 0); };
         auto km2 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 2, 0); };
         auto km1 = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ, 0); };

@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offse
 
 // STATS (diagnostic builds only, tools/stream_tune.hip): every wave leaves {cycles alive, cycles waiting, begin << 32 | end on
 // the 100 MHz clock, items} in stats[(block * waves + wave) * 4 ..]; waiting = storers: for production, producers: for ring room.
-// split / lg / bias / slots: see "this workgroup's range" below; slots_clear = the slot counters of a LATER launch, zeroed here
-// (the host goes round a few pairs of counters: a launch never finds its own dirty, whatever became of the one before)
+// split / lg / bias / slots: see "this workgroup's range" below (slots: three zeroed counters no other launch in flight uses)
 // NPW: positions waves (chunks of 1 KiB dealt round-robin among them)
 // QS: lattices whose tables a producer keeps alive (1 = one lattice at a time; > 1 = hit queue across lattices, d <= 7)
 template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false, int NPW = 1, int QS = 1>
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                                                                   int32_t* __restrict__ pos, int64_t capacity,
                                                                   int* __restrict__ err, int64_t e_begin, int64_t e_end,
                                                                   const int32_t* __restrict__ split, int lg, int bias,
-                                                                  unsigned int* __restrict__ slots, unsigned int* __restrict__ slots_clear,
+                                                                  unsigned int* __restrict__ slots,
                                                                   unsigned long long* __restrict__ stats = nullptr) {
     using L = Lat<D>;
     using PS = PStream<D>;
@@ -184,7 +183,8 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
     // ones -- with equal shares the even XCDs' workgroups end at 0.80 of the launch, on every box and buffer measured
     // (profiles/r04_workgroup_end_times.txt).  So every pair of shares (2 RR fine parts) is cut into a LARGE slot of
     // RR + bias and a SMALL one of RR - bias, and a workgroup takes the next free large slot if it runs on an even XCD
-    // (HW_REG_XCC_ID), the next free small one otherwise: two counters, one atomic per workgroup.  Workgroups go to the
+    // (HW_REG_XCC_ID), the next free small one otherwise: two counters (and a third that tells the last workgroup to
+    // zero them again), two atomics per workgroup.  Workgroups go to the
     // XCDs round-robin, but from where the dispatcher happens to stand (other streams' kernels move it:
     // tools/xcc_id_probe.hip), so blockIdx.x says nothing about the XCD; and whatever the dispatcher does, gridDim.x
     // workgroups take gridDim.x different slots -- if one kind runs out the other kind is taken.
@@ -204,9 +204,12 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
             unsigned t = atomicAdd(&slots[large], 1u);
             if (t >= half) { large ^= 1; t = atomicAdd(&slots[large], 1u); }
             idx = t < half ? (int)t : -1;                     // (-1: the counters were not zero when the launch began)
+            // the last workgroup to have taken its slot leaves the three counters zero for the next launch that uses them
+            // (also a replay of this very launch from a captured graph): nobody else touches them any more
+            __threadfence();
+            if (atomicAdd(&slots[2], 1u) == gridDim.x - 1u) { slots[0] = 0u; slots[1] = 0u; __threadfence(); slots[2] = 0u; }
         }
         slot_s[0] = large; slot_s[1] = idx;
-        if (blockIdx.x == 0 && slots_clear) { slots_clear[0] = 0u; slots_clear[1] = 0u; }
     }
     __syncthreads();
     if (slot_s[1] < 0) {

@@ -63,7 +63,7 @@ struct DeviceCtx {
 constexpr int SPLIT_MAX = 256;       // persistent workgroups of the stack write: one per CU of an MI355X
 constexpr int SPLIT_LG = 13;         // the scan's table cuts the stack into 1 << SPLIT_LG fine parts: 32 per workgroup
 constexpr int SPLIT_ENTRIES = (1 << SPLIT_LG) + 1;
-constexpr int N_SLOT_SETS = 8;       // pairs of slot counters of the stack write, used in turn
+constexpr int N_SLOT_SETS = 8;       // sets of slot counters of the stack write, used in turn
 // Fine parts (of 32) that the workgroup of an odd XCD hands to its even neighbour (stream_write.hpp: the odd XCDs of an
 // MI355X store ~20 % slower; sweep in profiles/r04_xcd_bias_sweep.txt).  tq_set_xcd_bias / TORICENV_XCD_BIAS = 0..16.
 constexpr int XCD_BIAS_DEFAULT = 5;
@@ -186,14 +186,14 @@ struct StreamCfg {
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, int* err, hipStream_t stream, int64_t first, int64_t count,
-                         const int32_t* split, unsigned int* slots, unsigned int* slots_clear) {
+                         const int32_t* split, unsigned int* slots) {
     using C = StreamCfg<D, (int)sizeof(OutT)>;
     // a workgroup's part of the stack is addressed with 32-bit element offsets
     if ((double)count * (2.0 * D * D) * (2.0 * D * D) / SPLIT_MAX * 1.5 > 2.0e9)    // (the largest share is 1.5 of the mean)
         return fail(TQ_E_INVALID, "lattice range too large for one stack write (%lld lattices of d=%d)", (long long)count, D);
     hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, C::NS, C::NP, C::CPW, C::RB, C::RP, false, C::NPW>), dim3(SPLIT_MAX),
                        dim3(64 * (C::NS + C::NPW + C::NP)), 0, stream, vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split,
-                       SPLIT_LG, D >= 7 ? xcd_bias() : 0, slots, slots_clear, (unsigned long long*)nullptr);
+                       SPLIT_LG, D >= 7 ? xcd_bias() : 0, slots, (unsigned long long*)nullptr);
     KCHECK();
     return TQ_OK;
 }
@@ -203,13 +203,13 @@ int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, 
 template <int D>
 int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                        int64_t capacity, int dtype, int* err, hipStream_t stream, int64_t first, int64_t count,
-                       const int32_t* split, unsigned int* slots = nullptr, unsigned int* slots_clear = nullptr) {
+                       const int32_t* split, unsigned int* slots = nullptr) {
     if (count == 0) return TQ_OK;
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots, slots_clear);
-        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots, slots_clear);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots, slots_clear);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots, slots_clear);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -243,8 +243,8 @@ struct tq_env {
     int32_t* split[2];     // cut points of the stack write, written by the scan (tq_persp_count); two tables take turns, so
     const int64_t* split_for[2];   // the scan of the next step does not overwrite what a running write reads; the offsets
     int split_last;        // array each belongs to, and which one was written last
-    unsigned int* slots;   // N_SLOT_SETS pairs of counters: the workgroups of a stack write take their shares by XCD (stream_write.hpp);
-    unsigned write_seq;    // write i counts in pair i % N and zeroes the pair N / 2 writes ahead
+    unsigned int* slots;   // N_SLOT_SETS sets of 4 counters: the workgroups of a stack write take their shares by XCD (stream_write.hpp)
+    unsigned write_seq;    // and leave them zero; write i uses set i % N, so N writes of one handle may be in flight
 };
 
 namespace {
@@ -452,7 +452,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc(&h->tblock, (size_t)tq::block_bytes(h->w, n_envs));
     alloc((void**)&h->split[0], (SPLIT_ENTRIES + 3) * sizeof(int32_t));
     alloc((void**)&h->split[1], (SPLIT_ENTRIES + 3) * sizeof(int32_t));
-    alloc((void**)&h->slots, N_SLOT_SETS * 2 * sizeof(unsigned int));
+    alloc((void**)&h->slots, N_SLOT_SETS * 4 * sizeof(unsigned int));
     h->reset_epoch = 0;
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
@@ -668,11 +668,9 @@ int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count
         if (offsets == h->split_for[h->split_last]) split = h->split[h->split_last];
         else if (offsets == h->split_for[h->split_last ^ 1]) split = h->split[h->split_last ^ 1];
     }
-    unsigned int* slots = h->slots + 2 * (h->write_seq % N_SLOT_SETS);
-    unsigned int* slots_clear = h->slots + 2 * ((h->write_seq + N_SLOT_SETS / 2) % N_SLOT_SETS);
-    ++h->write_seq;
+    unsigned int* slots = h->slots + 4 * (h->write_seq++ % N_SLOT_SETS);
 #define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream, first, count, \
-        split, slots, slots_clear)) return rc
+        split, slots)) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;

@@ -160,6 +160,16 @@ void one(Ctx& c, bool stats, bool is_ref) {
                se[0], se[25], se[128], mean, se[230], se[255], bmax);
         printf("      mean end by XCD (workgroup %% 8):");
         for (int x = 0; x < 8; ++x) { double m = 0; for (int g = x; g < 256; g += 8) m += en[g] / 32; printf(" %.1f", m); }
+        printf("\n      shader clock by XCD (cycles alive / time alive of the storers, MHz):");
+        for (int x = 0; x < 8; ++x) {
+            double cyc = 0, us = 0;
+            for (int g = x; g < 256; g += 8) for (int w = 0; w < NS; ++w) {
+                const unsigned long long* o = &h[((size_t)g * WV + w) * 4];
+                if (!o[2]) continue;
+                cyc += (double)o[0]; us += (double)((uint32_t)o[2] - (uint32_t)(o[2] >> 32)) / 100.0;
+            }
+            printf(" %.0f", us > 0 ? cyc / us : 0.0);
+        }
         printf("\n      mean end by position in the stack (32 consecutive workgroups each):");
         for (int x = 0; x < 8; ++x) { double m = 0; for (int g = 32 * x; g < 32 * x + 32; ++g) m += en[g] / 32; printf(" %.1f", m); }
         printf("\n");

@@ -15,7 +15,7 @@
 #include <random>
 #include <vector>
 
-#include "stream_write.hpp"
+#include "stream_write.hpp"   // (the kernel is called with its 257-entry table: equal shares (lg = 8, bias 0, no slot counters), as when this harness was written)
 #include "lattice_write_r02.hpp"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -102,7 +102,7 @@ void stats_run(const uint64_t* vp, int64_t N, const int64_t* off, float* out, in
     CK(hipMalloc(&st, sizeof(unsigned long long) * G * WV * 4));
     CK(hipMemset(st, 0, sizeof(unsigned long long) * G * WV * 4));
     hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS, NP, CPW, 14, 12, true>), dim3(G), dim3(64 * WV), 0, 0, vp, N, off, out, pos, cap,
-                       err, (int64_t)0, N, split, st);
+                       err, (int64_t)0, N, split, 8, 0, (unsigned int*)nullptr, st);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)G * WV * 4);
     CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
@@ -185,7 +185,7 @@ int run(int64_t N, double q) {
             unsigned long long* st; CK(hipMalloc(&st, 8 * 256 * WV * 4)); CK(hipMemset(st, 0, 8 * 256 * WV * 4));
             hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)(r[1] - r[0])), dim3(64), 0, 0, vp, N, off, a, pa, Pr, err, r[0], r[1]);
             hipLaunchKernelGGL(tq::k_split, dim3((256 + 1 + 3) / 4), dim3(256), 0, 0, (const int64_t*)off, r[0], r[1], split2, 8);
-            hipLaunchKernelGGL((tq::k_persp_stream<D, float, 4, 11, 8, 14, 12, true>), dim3(256), dim3(1024), 0, 0, vp, N, off, b, pb, Pr, err, r[0], r[1], (const int32_t*)split2, st);
+            hipLaunchKernelGGL((tq::k_persp_stream<D, float, 4, 11, 8, 14, 12, true>), dim3(256), dim3(1024), 0, 0, vp, N, off, b, pb, Pr, err, r[0], r[1], (const int32_t*)split2, 8, 0, (unsigned int*)nullptr, st);
             hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)a, (const uint32_t*)b, Pr * NQ, badr);
             hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)pa, (const uint32_t*)pb, Pr * 3, badr);
             unsigned long long nb; CK(hipMemcpy(&nb, badr, 8, hipMemcpyDeviceToHost));
@@ -197,7 +197,7 @@ int run(int64_t N, double q) {
                    (long long)r[0], (long long)r[1], (long long)Pr, nb, alive, lastwg);
             // the same with the product instantiation (no statistics)
             CK(hipMemset(b, 0x77, (size_t)Pr * NQ * 4)); CK(hipMemset(pb, 0x77, (size_t)Pr * 12)); CK(hipMemset(badr, 0, 8));
-            hipLaunchKernelGGL((tq::k_persp_stream<D, float, 4, 11, 8, 14, 12>), dim3(256), dim3(1024), 0, 0, vp, N, off, b, pb, Pr, err, r[0], r[1], (const int32_t*)nullptr, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL((tq::k_persp_stream<D, float, 4, 11, 8, 14, 12>), dim3(256), dim3(1024), 0, 0, vp, N, off, b, pb, Pr, err, r[0], r[1], (const int32_t*)nullptr, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr);
             hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)a, (const uint32_t*)b, Pr * NQ, badr);
             hipLaunchKernelGGL(k_diff, dim3(256), dim3(256), 0, 0, (const uint32_t*)pa, (const uint32_t*)pb, Pr * 3, badr);
             CK(hipMemcpy(&nb, badr, 8, hipMemcpyDeviceToHost));
@@ -232,7 +232,7 @@ int run(int64_t N, double q) {
     printf("output buffers of different physical make-up, the same launches on each (GB/s of algorithmic bytes; memset: stack bytes only):\n");
     for (int b = 0; b < 8; ++b) {
         float* ob = bufs[b];
-        auto ks = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NSP, NPP, 8, 14, 12>), dim3(256), dim3(64 * (NSP + 1 + NPP)), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, (unsigned long long*)nullptr); };
+        auto ks = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NSP, NPP, 8, 14, 12>), dim3(256), dim3(64 * (NSP + 1 + NPP)), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
         auto kl = [&] { hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N); };
         auto km = [&] { (void)hipMemsetAsync(ob, 1, (size_t)P * NQ * 4, 0); };
         CK(hipMemset(ob, 0x77, (size_t)P * NQ * 4)); CK(hipMemset(p2, 0x77, (size_t)P * 12)); CK(hipMemset(bad, 0, 8));
@@ -271,7 +271,7 @@ int run(int64_t N, double q) {
             const int64_t e1 = (int64_t)(N * f);
             const int64_t Pr = ho[e1];
             const double by = (double)Pr * (NQ * 4 + 12) + (double)e1 * NQ;
-            auto ks = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NSP, NPP, 8, 14, 12>), dim3(256), dim3(64 * (NSP + 1 + NPP)), 0, 0, vp, N, off, ob, p2, Pr, err, (int64_t)0, e1, (const int32_t*)nullptr, (unsigned long long*)nullptr); };
+            auto ks = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NSP, NPP, 8, 14, 12>), dim3(256), dim3(64 * (NSP + 1 + NPP)), 0, 0, vp, N, off, ob, p2, Pr, err, (int64_t)0, e1, (const int32_t*)nullptr, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr); };
             float a = 0; for (int r = 0; r < 6; ++r) { float x = t.run(ks); if (r) a += x; }
             printf("    f=%.2f  spacing %8.3f MB  %6.0f GB/s\n", f, (double)Pr * NQ * 4 / 256 / 1e6, by / (a / 5) / 1e6);
         }
@@ -280,7 +280,7 @@ int run(int64_t N, double q) {
     for (int which : {fast, slow}) {
         float* ob = bufs[which];
         printf("storer / producer waves and window size, on buffer %d (%s):\n", which, which == fast ? "fastest" : "slowest");
-#define SW(NS, NP, CPW) { auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS, NP, CPW, 14, 12>), dim3(256), dim3(64 * (NS + 1 + NP)), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, (unsigned long long*)nullptr); }; \
+#define SW(NS, NP, CPW) { auto k = [&] { hipLaunchKernelGGL((tq::k_persp_stream<D, float, NS, NP, CPW, 14, 12>), dim3(256), dim3(64 * (NS + 1 + NP)), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N, split, 8, 0, (unsigned int*)nullptr, (unsigned long long*)nullptr); }; \
         printf("    NS=%d NP=%2d CPW=%2d  %6.0f GB/s\n", NS, NP, CPW, timeit(k)); }
         SW(4, 11, 8) SW(2, 13, 8) SW(4, 7, 8) SW(4, 3, 8) SW(6, 9, 8) SW(8, 7, 8) SW(4, 11, 4) SW(4, 11, 32) SW(2, 5, 8)
         auto kl = [&] { hipLaunchKernelGGL((tq::k_persp_write<D, float, 64>), dim3((unsigned)N), dim3(64), 0, 0, vp, N, off, ob, p2, P, err, (int64_t)0, N); };

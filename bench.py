@@ -41,6 +41,7 @@ serial path (run_serial).
 """
 import argparse
 import contextlib
+import gc
 import json
 import os
 import socket
@@ -476,11 +477,15 @@ def time_explore_leg(T, torch, env, n, d, seed, tdtype, flush, device, steps, wa
     leg.pick_stack(candidates, kinds)
     w = leg.warm(warm)
     leg.prepare(steps, event_every)
+    gc.disable()                        # no collection inside the timed region: what it frees (tq_stack_free synchronises the device; the driver
+                                        # wipes freed memory in the background) would land in it.  Not gc.collect() here either -- measured: the
+                                        # wipe of what THAT frees slows the first timed writes by 5-38 %
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     leg.run(steps, event_every)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    gc.enable()
     p_all, _ = leg.perspectives()
     P = float(p_all.sum().item())
     out = {"lattices": n, "d": d, "steps": steps, "warmup": warm, "value": n * steps / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / steps,
@@ -674,6 +679,7 @@ def run_explore(ctx):
         w = leg.warm(W, reprobe=not args.no_events)
         leg.prepare(K, EV)
         state["tg"] = gather_
+        gc.disable()                    # no collection (and no free of device memory) inside the timed region
         barrier()
         t0 = time.perf_counter()
         leg.run(K, EV)
@@ -682,6 +688,7 @@ def run_explore(ctx):
                 state["tg"].wait()
         barrier()
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        gc.enable()
         if dist_on:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item()), w

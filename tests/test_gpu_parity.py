@@ -1120,6 +1120,18 @@ def test_unequal_workgroup_shares_write_the_same_stack(T, d, n, dtype):
             want = torch.as_tensor(cper[i:i + step], device=gpu.device)
             assert torch.equal(out[0][0][:P][i:i + step].to(torch.float32), want.to(torch.float32))
         assert L.tq_set_xcd_bias(17) < 0 and L.tq_set_xcd_bias(-1) < 0 and L.tq_get_xcd_bias() == 3
+        if d == 7:
+            # the probe: candidates of ONE kind write at one rate -> the search is extended once, the first ones still allocated;
+            # the share setting is checked on the kept buffer (and whatever it decides, the stack is the same)
+            L.tq_set_xcd_bias(default)
+            best, rep = gpu.pickStackBuffer(3, capacity=P + 8, kinds=("torch",), launches=4)
+            added = rep["candidates_added_because_uniform"]
+            assert added in (0, 3) and rep["candidates"] == 3 + added == len(rep["write_ms"]) == len(rep["kinds"])
+            assert (added == 3) == (min(rep["write_ms"][:3]) > 0.93 * rep["write_ms"][0] and rep["write_ms"][0] >= 0.1)
+            assert "xcd_bias" in rep and rep["xcd_bias"]["bias"] in (0, T.configured_xcd_bias())
+            gpu.writePerspectives(best, None, offsets)
+            gpu.check()
+            assert torch.equal(best[:P], out[0][0][:P])
     finally:
         L.tq_set_xcd_bias(default)
         gpu.close()

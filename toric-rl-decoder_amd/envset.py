@@ -441,7 +441,7 @@ class EnvSet:
 
     def pickStackBuffer(self, candidates=4, dtype=torch.float32, capacity=None, positions=None, launches=10,
                         kinds=("torch", "chunked"), park=False, first=0, count=None, timer=None, passes=2, among=None,
-                        check_shares=True):
+                        check_shares=True, extend_if_uniform=True):
         """Set-up helper: allocate ``candidates`` stack buffers (``capacity`` perspectives each, default the worst
         case no_envs * 2*d*d), time the stack write on each of them and keep the fastest.  On MI355X the rate of a
         write stream into a buffer depends on the buffer AND on the stream's shape (5.2-6.9 TB/s for this kernel,
@@ -462,7 +462,9 @@ class EnvSet:
         ``first`` / ``count``: the default timer writes that lattice range only (a consumer that walks the batch in ranges
         with a small buffer: ``capacity`` is then the small buffer's).  ``check_shares``: also time the kept buffer with
         equal shares per workgroup against the library's unequal ones (toricenv.h: tq_set_xcd_bias) and keep the faster
-        setting (report["xcd_bias"]).  Synchronises; never call it in the step loop."""
+        setting (report["xcd_bias"]).  ``extend_if_uniform``: when no candidate writes 7 % faster than candidate 0, allocate
+        and time as many candidates again (the first ones stay allocated; bounded by half of the free memory) -- once.
+        Synchronises; never call it in the step loop."""
         d, nq = self.size, 2 * self.size * self.size
         cap = self.no_envs * nq if capacity is None else int(capacity)
         if positions is None:
@@ -477,25 +479,32 @@ class EnvSet:
             with torch.cuda.device(self.device):
                 free = torch.cuda.mem_get_info()[0]
             wanted = max(1, int(candidates))
-            fit = max(1, min(wanted, int(0.5 * free // max(nbytes, 1))))
-            for k in range(fit):
-                kind = kinds[0] if k == 0 or len(kinds) == 1 else kinds[1 + (k - 1) % (len(kinds) - 1)]
-                c = None
-                try:
-                    if kind == "chunked":
-                        try:
-                            c = alloc_stack(cap, d, dtype, self.device)
-                        except _lib.ToricEnvError:                # no virtual-memory API on this driver (or no memory): plain allocation
-                            kind = "torch"
-                    if c is None:
-                        c = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
-                except torch.OutOfMemoryError:
-                    if not keep:
-                        raise
-                    break                                         # the candidates that exist will do
-                used.append("torch.empty" if kind == "torch" else "alloc_stack (2 MiB chunks)")
-                keep.append(c)
-                c = None
+            room = int(0.5 * free // max(nbytes, 1))              # candidates that may exist at once
+            fit = max(1, min(wanted, room))
+
+            def allocate(count):
+                """``count`` more candidates (fewer when the device runs out); -> how many there are now."""
+                for _ in range(count):
+                    k = len(keep)
+                    kind = kinds[0] if k == 0 or len(kinds) == 1 else kinds[1 + (k - 1) % (len(kinds) - 1)]
+                    c = None
+                    try:
+                        if kind == "chunked":
+                            try:
+                                c = alloc_stack(cap, d, dtype, self.device)
+                            except _lib.ToricEnvError:            # no virtual-memory API on this driver (or no memory): plain allocation
+                                kind = "torch"
+                        if c is None:
+                            c = torch.empty((cap, 2, d, d), dtype=dtype, device=self.device)
+                    except torch.OutOfMemoryError:
+                        if not keep:
+                            raise
+                        break                                     # the candidates that exist will do
+                    used.append("torch.empty" if kind == "torch" else "alloc_stack (2 MiB chunks)")
+                    keep.append(c)
+                    c = None
+                return len(keep)
+            allocate(fit)
         if timer is None:
             off = self.perspectiveCounts()[1].clone()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -515,6 +524,21 @@ class EnvSet:
         for _ in range(max(1, int(passes))):
             for i, c in enumerate(keep):
                 samples[i] += list(timer(c, per_pass))
+        # No candidate stands out (every one within 7 % of candidate 0)?  On some boxes the first tens of GB a process
+        # allocates ALL write at the slow rate and faster buffers only turn up behind them (profiles/README.md, round 4:
+        # 24 x 2.5 GB at 0.358-0.368 ms, then, for the next leg, candidates 12 and 16-20 of 24 x 5 GB at 0.57 against 0.71 ms).
+        # So the search goes on once, with as many candidates again, WHILE the first ones stay allocated.
+        extended = 0
+        if among is None and extend_if_uniform and len(keep) >= 3 and len(keep) < room:
+            ms0 = [float(np.median(x)) for x in samples]
+            if min(ms0) > 0.93 * ms0[0] and ms0[0] >= 0.1:         # (a write of under 0.1 ms is not about bandwidth)
+                before = len(keep)
+                extended = allocate(min(before, room - before)) - before
+                samples += [[] for _ in range(extended)]
+                torch.cuda.synchronize(self.device)
+                for _ in range(max(1, int(passes))):
+                    for i in range(before, len(keep)):
+                        samples[i] += list(timer(keep[i], per_pass))
         self.check()
         ms = [float(np.median(x)) for x in samples]
         chosen = int(np.argmin(ms))
@@ -522,7 +546,7 @@ class EnvSet:
         rejected = [x for x in keep if x is not best]
         if park:
             self._parked = [x for x in getattr(self, "_parked", []) if all(x is not y for y in keep)] + rejected
-        report = {"candidates": len(ms), "candidates_asked": int(candidates) if among is None else len(ms), "write_ms": ms, "write_ms_min": [float(min(x)) for x in samples], "chosen": chosen,
+        report = {"candidates": len(ms), "candidates_asked": int(candidates) if among is None else len(ms), "candidates_added_because_uniform": extended, "write_ms": ms, "write_ms_min": [float(min(x)) for x in samples], "chosen": chosen,
                   "probe_ms_chosen": ms[chosen], "writes_per_candidate": len(samples[0]), "kinds": used,
                   "addresses": [hex(x.data_ptr()) for x in keep]}
         # The shares of the write's workgroups (tq_set_xcd_bias: the even XCDs' workgroups take more of the stack) against

@@ -108,8 +108,8 @@ int tq_stack_free(void* ptr);
 /* The stack write runs one persistent workgroup per CU, each with a fixed contiguous share of the stack, dealt to the
  * XCDs round-robin.  On MI355X the CUs of the odd XCDs store this stream ~20 % slower than those of the even ones (every
  * box and buffer measured: profiles/r04_workgroup_end_times.txt), so of every pair of workgroups the even one takes
- * 32 + bias and the odd one 32 - bias of the pair's 64 fine parts -- for d >= 7 and stacks of 64 MB and more (smaller
- * lattices are bound by the producers, not by the stores: there unequal shares only cost).  Default 5 (or the
+ * 32 + bias and the odd one 32 - bias of the pair's 64 fine parts -- for d >= 7, f32 / f16 / bf16 stacks of 64 MB and more
+ * (smaller lattices and the u8 stack are bound by the producers, not by the stores: there unequal shares only cost).  Default 5 (or the
  * environment variable TORICENV_XCD_BIAS, read once); 0 = equal shares; process-wide; changes the speed of
  * tq_persp_write*, never its result.  EnvSet.pickStackBuffer checks the setting against equal shares on the caller's
  * own write. */

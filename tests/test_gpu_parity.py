@@ -1076,7 +1076,7 @@ def test_scan_after_a_large_stack_leaves_no_stale_cut_points(T):
     gpu.close()
 
 
-@pytest.mark.parametrize("d,n,dtype", [(7, 24576, torch.float32), (9, 8192, torch.bfloat16), (11, 8192, torch.uint8)])
+@pytest.mark.parametrize("d,n,dtype", [(7, 24576, torch.float32), (9, 8192, torch.bfloat16), (11, 8192, torch.float16), (7, 32768, torch.uint8)])
 def test_unequal_workgroup_shares_write_the_same_stack(T, d, n, dtype):
     """tq_set_xcd_bias: the workgroups of even XCDs take more of the stack than those of odd XCDs (d >= 7, stacks of
     64 MB and more).  Whatever the shares -- equal, the default, the extreme 48 : 16 -- the stack, the positions and

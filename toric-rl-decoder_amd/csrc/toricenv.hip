@@ -66,6 +66,8 @@ constexpr int SPLIT_ENTRIES = (1 << SPLIT_LG) + 1;
 constexpr int N_SLOT_SETS = 8;       // sets of slot counters of the stack write, used in turn
 // Fine parts (of 32) that the workgroup of an odd XCD hands to its even neighbour (stream_write.hpp: the odd XCDs of an
 // MI355X store ~20 % slower; sweep in profiles/r04_xcd_bias_sweep.txt).  tq_set_xcd_bias / TORICENV_XCD_BIAS = 0..16.
+// Used for d >= 7 and 32- / 16-bit stacks: smaller lattices and the u8 stack are bound by the producers, where unequal
+// shares only cost (u8, d=7, in the two-stream loop: 0.0931 ms with equal shares, 0.1000 ms with 37 : 27).
 constexpr int XCD_BIAS_DEFAULT = 5;
 static std::atomic<int> g_xcd_bias{-1};
 static int xcd_bias() {
@@ -193,7 +195,7 @@ int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, 
         return fail(TQ_E_INVALID, "lattice range too large for one stack write (%lld lattices of d=%d)", (long long)count, D);
     hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, C::NS, C::NP, C::CPW, C::RB, C::RP, false, C::NPW>), dim3(SPLIT_MAX),
                        dim3(64 * (C::NS + C::NPW + C::NP)), 0, stream, vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split,
-                       SPLIT_LG, D >= 7 ? xcd_bias() : 0, slots, (unsigned long long*)nullptr);
+                       SPLIT_LG, (D >= 7 && sizeof(OutT) >= 2) ? xcd_bias() : 0, slots, (unsigned long long*)nullptr);
     KCHECK();
     return TQ_OK;
 }

@@ -552,7 +552,7 @@ class EnvSet:
         # The shares of the write's workgroups (tq_set_xcd_bias: the even XCDs' workgroups take more of the stack) against
         # equal shares, on the buffer that was kept: the setting rests on a measured asymmetry of MI355X, so it is checked
         # where it is used.  Process-wide; d <= 5 never uses it.
-        if check_shares and d >= 7:
+        if check_shares and d >= 7 and dtype != torch.uint8:
             L = self._L
             b0 = configured_xcd_bias()                          # not tq_get_xcd_bias(): an earlier probe of this process may have switched it off
             if b0 > 0:

@@ -129,7 +129,10 @@ def test_bench_json_contract():
     assert set(nn["variants"]) == {"f32", "bf16"} and nn["variants"]["bf16"]["stack_dtype"] == "bf16"
     pr = j["stack_buffer_probe"]                              # set-up probe of the stack buffer's placement, reported in full
     assert pr["kinds"][0] == "torch.empty" and len(pr["write_ms"]) == pr["candidates"] >= 2 and 0 <= pr["chosen"] < pr["candidates"]
-    assert pr["writes_per_candidate"] >= 10 and abs(pr["probe_ms_chosen"] - pr["write_ms"][pr["chosen"]]) < 1e-9 or "reprobe" in pr
+    # the figure the timed region is held against is taken behind the settling passes; the one from the candidates' bursts is kept beside it
+    assert pr["writes_per_candidate"] >= 10 and pr["probe_ms_chosen"] > 0 and pr["probe_ms_in_bursts"] > 0 and pr["settle_steps"] >= 1
+    assert pr["candidates_added_because_uniform"] in (0, pr["candidates"] // 2)
+    assert r["workgroup_shares"]["xcd_bias"] in range(0, 17)
     # every leg explains itself: what the probe promised, what the timed region delivered, what a default allocation would give
     assert r["probe_ms_chosen"] > 0 and abs(r["timed_write_ms"] - r["avg_launch_ms"]) < 1e-9 and r["first_launch_ms"] > 0
     assert abs(r["timed_over_probe"] - r["timed_write_ms"] / r["probe_ms_chosen"]) < 1e-9

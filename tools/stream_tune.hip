@@ -88,7 +88,7 @@ void launch_kind(Ctx& c, int grid, const int32_t* sp, unsigned long long* st) {
     if constexpr (KIND == 2) {
         hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, STATS, NPW, QS>), dim3(grid), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
                            (OutT*)c.out, c.pos, c.P, c.err, (int64_t)0, c.N, sp ? c.split_fine : nullptr, grid == 256 ? 13 : 14, c.bias,
-                           c.ticket + 8 + 4 * (c.launches % 8), st);
+                           c.ticket + 8 + tq::STREAM_SLOT_WORDS * (c.launches % 8), st);
         ++c.launches;
     } else if constexpr (KIND == 1) {
         hipLaunchKernelGGL((tqr::k_persp_stream<D, OutT, NS, NP, CPW, RB, RP, STATS, NPW, SCHED>), dim3(grid), dim3(64 * WV), 0, 0, c.vp, c.N, c.off,
@@ -142,7 +142,7 @@ void one(Ctx& c, bool stats, bool is_ref) {
         for (int g = 0; g < 256; ++g) for (int w = w0; w < w1; ++w) {
             const unsigned long long* o = &h[((size_t)g * WV + w) * 4];
             if (!o[0]) continue;
-            tot += o[0]; wa += o[1]; items += o[3]; mx = std::max(mx, (double)o[0]); ++n;
+            tot += o[0]; wa += o[1]; items += (double)(o[3] & 0xFFFFFFFFull); mx = std::max(mx, (double)o[0]); ++n;
         }
         if (n) printf("      %-10s waves %5d  alive %9.0f cyc (max %9.0f)  waiting for %s %5.1f %%  %s %5.1f %%  items/wave %7.1f  busy cyc/item %7.0f\n",
                       role, n, tot / n, mx, a_name, 100 * wa / tot, b_name, 100 * wb / tot, items / n, (tot - wa - wb) / std::max(1.0, items));
@@ -169,6 +169,15 @@ void one(Ctx& c, bool stats, bool is_ref) {
                 cyc += (double)o[0]; us += (double)((uint32_t)o[2] - (uint32_t)(o[2] >> 32)) / 100.0;
             }
             printf(" %.0f", us > 0 ? cyc / us : 0.0);
+        }
+        {   // when a workgroup's storers began their first trip (the first bytes leave the CU), us after the workgroup began
+            double mn = 1e9, mx = 0, sum = 0; int n = 0;
+            for (int g = 0; g < 256; ++g) {
+                double f = 1e9;
+                for (int w = 0; w < NS; ++w) { const unsigned long long x = h[((size_t)g * WV + w) * 4 + 3] >> 32; if (x) f = std::min(f, (double)x / 100.0); }
+                if (f < 1e9) { mn = std::min(mn, f); mx = std::max(mx, f); sum += f; ++n; }
+            }
+            if (n) printf("\n      first trip of a workgroup's storers begins after: min %.1f  mean %.1f  max %.1f us", mn, sum / n, mx);
         }
         printf("\n      mean end by position in the stack (32 consecutive workgroups each):");
         for (int x = 0; x < 8; ++x) { double m = 0; for (int g = 32 * x; g < 32 * x + 32; ++g) m += en[g] / 32; printf(" %.1f", m); }
@@ -262,7 +271,7 @@ int run(int64_t N, double q, const char* tname) {
                            (const int64_t*)part, off, (int32_t*)nullptr, N, sf, tqr::STREAM_DYN_LG);
         CK(hipDeviceSynchronize());
         c.split_fine = sf;
-        CK(hipMalloc(&c.ticket, 160)); CK(hipMemset(c.ticket, 0, 160));   // 8 ticket counters (runs experiment) + 8 sets of 4 slot counters
+        CK(hipMalloc(&c.ticket, 4 * (8 + 8 * tq::STREAM_SLOT_WORDS))); CK(hipMemset(c.ticket, 0, 4 * (8 + 8 * tq::STREAM_SLOT_WORDS)));   // 8 ticket counters (runs experiment) + 8 sets of slot counters
     }
     CK(hipMalloc(&c.ref, out_bytes)); CK(hipMalloc(&c.pref, (size_t)P * 12 + 4096)); CK(hipMalloc(&c.pos, (size_t)P * 12 + 4096)); CK(hipMalloc(&c.bad, 8));
     // candidate buffers: the product configuration on each, the fastest is used for the sweep

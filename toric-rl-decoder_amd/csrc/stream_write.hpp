@@ -25,6 +25,7 @@
 namespace tq {
 
 constexpr int ERR_INTERNAL = 32;
+constexpr int STREAM_SLOT_WORDS = 4;                           // slot counters of one launch of k_persp_stream: large, small, done (+ 1 pad)
 constexpr int STREAM_SPIN_LIMIT = 1 << 21;
 
 // Hand-off words live in LDS, which one workgroup's waves see coherently, and a wave's LDS operations execute in
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_split(const int64_t* __restrict__ offse
 
 // STATS (diagnostic builds only, tools/stream_tune.hip): every wave leaves {cycles alive, cycles waiting, begin << 32 | end on
 // the 100 MHz clock, items} in stats[(block * waves + wave) * 4 ..]; waiting = storers: for production, producers: for ring room.
-// split / lg / bias / slots: see "this workgroup's range" below (slots: three zeroed counters no other launch in flight uses)
+// split / lg / bias / slots: see "this workgroup's range" below (slots: STREAM_SLOT_WORDS zeroed words no other launch in flight uses)
 // NPW: positions waves (chunks of 1 KiB dealt round-robin among them)
 // QS: lattices whose tables a producer keeps alive (1 = one lattice at a time; > 1 = hit queue across lattices, d <= 7)
 template <int D, typename OutT, int NS, int NP, int CPW, int RB_LOG, int RP_LOG, bool STATS = false, int NPW = 1, int QS = 1>
@@ -144,13 +145,13 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                                                                   unsigned long long* __restrict__ stats = nullptr) {
     using L = Lat<D>;
     using PS = PStream<D>;
-    unsigned long long t_begin = 0, t_a = 0, t_rt = 0, n_items = 0;
+    unsigned long long t_begin = 0, t_a = 0, t_rt = 0, n_items = 0, t_first = 0;
     if (STATS) { t_begin = __builtin_readcyclecounter(); t_rt = __builtin_amdgcn_s_memrealtime(); }
     auto stats_out = [&](int wv, int ln) {
         if (STATS && ln == 0) {                              // o[2]: the wave's life on the constant 100 MHz clock, begin << 32 | end
             unsigned long long* o = stats + ((size_t)blockIdx.x * (NS + NPW + NP) + wv) * 4;
             o[0] = __builtin_readcyclecounter() - t_begin; o[1] = t_a;
-            o[2] = (t_rt << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull); o[3] = n_items;
+            o[2] = (t_rt << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull); o[3] = n_items | (t_first << 32);   // (storers: + when the first trip began, 10 ns units)
         }
     };
     using Enc = OutEnc<OutT>;
@@ -192,11 +193,14 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
     // passes bias = 0 for d <= 5, whose launches are bound by the producers (d=5: 108 -> 121 us with 5 / 32,
     // profiles/r04_xcd_bias_sweep.txt).
     const int RR = (1 << lg) / (int)gridDim.x;
-    if (!slots || (offsets[e_end] - offsets[e_begin]) * (int64_t)(NQ * sizeof(OutT)) < (int64_t)(64 << 20) || bias >= RR) bias = 0;
+    // a small stack is not bound by the stores: equal shares, and no counters (their atomic's round trip across the XCDs is
+    // ~3 us at the start of a launch: nothing beside 280 us, a fifth of a 15 us launch)
+    if (!slots || bias >= RR || (offsets[e_end] - offsets[e_begin]) * (int64_t)(NQ * sizeof(OutT)) < (int64_t)(64 << 20)) bias = 0;
+    const bool take = bias > 0;
     __shared__ int slot_s[2];
     if (threadIdx.x == 0) {
         int large = !(blockIdx.x & 1), idx = (int)(blockIdx.x >> 1);
-        if (bias > 0) {
+        if (take) {
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             large = !(xcc & 1u);
@@ -204,14 +208,25 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
             unsigned t = atomicAdd(&slots[large], 1u);
             if (t >= half) { large ^= 1; t = atomicAdd(&slots[large], 1u); }
             idx = t < half ? (int)t : -1;                     // (-1: the counters were not zero when the launch began)
-            // the last workgroup to have taken its slot leaves the three counters zero for the next launch that uses them
-            // (also a replay of this very launch from a captured graph): nobody else touches them any more
-            __threadfence();
-            if (atomicAdd(&slots[2], 1u) == gridDim.x - 1u) { slots[0] = 0u; slots[1] = 0u; __threadfence(); slots[2] = 0u; }
+            // (one counter per kind, 128 workgroups on each: spreading them over eight counters per kind was measured and
+            // changes nothing -- the ~3 us this adds to a launch's start are the round trip of ONE device-scope atomic)
         }
         slot_s[0] = large; slot_s[1] = idx;
     }
+    // (the rings and hand-off words meanwhile: they do not depend on the range)
+    for (uint32_t i = threadIdx.x; i < (1u << RB_LOG) / 4; i += blockDim.x) reinterpret_cast<uint4*>(S.bits)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x == 0) S.abort = 0u;
+    if (threadIdx.x < NP) S.pq[threadIdx.x] = 0u;
+    if (threadIdx.x < NPW) S.pcons[threadIdx.x] = 0u;
+    if (threadIdx.x < NS) S.cons[threadIdx.x] = 0u;          // (a lower bound of "the first element storer s has not taken yet")
     __syncthreads();
+    if (threadIdx.x == 64 * NS && take) {                    // (a positions wave: thread 0's wave stores the range's first window)
+        // the last workgroup to have taken its slot leaves the counters zero for the next launch that uses them
+        // (also a replay of this very launch from a captured graph): nobody else touches them any more.  Off the
+        // critical path: only this thread's wave waits for the answer.
+        __threadfence();
+        if (atomicAdd(&slots[2], 1u) == gridDim.x - 1u) { slots[0] = 0u; slots[1] = 0u; __threadfence(); slots[2] = 0u; }
+    }
     if (slot_s[1] < 0) {
         if (threadIdx.x == 0) atomicOr(err, ERR_INTERNAL);
         return;
@@ -289,14 +304,6 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
     const bool has_stack = a1 > a0, has_pos = pos != nullptr && pa1 > pa0;
     if (!has_stack && !has_pos) return;                      // uniform over the workgroup
 
-    // ---- ring and hand-off words
-    for (uint32_t i = threadIdx.x; i < (1u << RB_LOG) / 4; i += blockDim.x) reinterpret_cast<uint4*>(S.bits)[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (threadIdx.x == 0) S.abort = 0u;
-    if (threadIdx.x < NP) S.pq[threadIdx.x] = 0u;
-    if (threadIdx.x < NPW) S.pcons[threadIdx.x] = 0u;
-    if (threadIdx.x < NS) S.cons[threadIdx.x] = a0;
-    __syncthreads();
-
     // bounded wait: until pred(), false when the workgroup gave up
     auto give_up = [&]() {
         if (lane == 0) { __hip_atomic_store(&S.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); atomicOr(err, ERR_INTERNAL); }
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                     lds_after_peek();
                     if (STATS) t_a += __builtin_readcyclecounter() - t0;
                 }
-                if (STATS) ++n_items;
+                if (STATS) { if (!n_items) t_first = __builtin_amdgcn_s_memrealtime() - t_rt; ++n_items; }
                 if (first) {
                     first = false;
                     if (s == 0 && a0 && lane < (int)(a0 / 32u)) S.bits[lane] = 0u;   // ring words in front of a0 (stored by the previous range)

@@ -245,7 +245,7 @@ struct tq_env {
     int32_t* split[2];     // cut points of the stack write, written by the scan (tq_persp_count); two tables take turns, so
     const int64_t* split_for[2];   // the scan of the next step does not overwrite what a running write reads; the offsets
     int split_last;        // array each belongs to, and which one was written last
-    unsigned int* slots;   // N_SLOT_SETS sets of 4 counters: the workgroups of a stack write take their shares by XCD (stream_write.hpp)
+    unsigned int* slots;   // N_SLOT_SETS sets of STREAM_SLOT_WORDS counters: the workgroups of a stack write take their shares by XCD (stream_write.hpp)
     unsigned write_seq;    // and leave them zero; write i uses set i % N, so N writes of one handle may be in flight
 };
 
@@ -454,7 +454,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     alloc(&h->tblock, (size_t)tq::block_bytes(h->w, n_envs));
     alloc((void**)&h->split[0], (SPLIT_ENTRIES + 3) * sizeof(int32_t));
     alloc((void**)&h->split[1], (SPLIT_ENTRIES + 3) * sizeof(int32_t));
-    alloc((void**)&h->slots, N_SLOT_SETS * 4 * sizeof(unsigned int));
+    alloc((void**)&h->slots, N_SLOT_SETS * tq::STREAM_SLOT_WORDS * sizeof(unsigned int));
     h->reset_epoch = 0;
     if (e != hipSuccess) { tq_destroy(h); return fail(TQ_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
     if (int rc = get_lut(device, d, nullptr, &h->lut)) { tq_destroy(h); return rc; }
@@ -670,7 +670,7 @@ int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count
         if (offsets == h->split_for[h->split_last]) split = h->split[h->split_last];
         else if (offsets == h->split_for[h->split_last ^ 1]) split = h->split[h->split_last ^ 1];
     }
-    unsigned int* slots = h->slots + 4 * (h->write_seq++ % N_SLOT_SETS);
+    unsigned int* slots = h->slots + tq::STREAM_SLOT_WORDS * (h->write_seq++ % N_SLOT_SETS);
 #define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream, first, count, \
         split, slots)) return rc
     DISPATCH_D(h->d, CALL)

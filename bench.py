@@ -427,7 +427,7 @@ class ExploreLeg:
             r["default_buffer"] = {"kind": self.probe["kinds"][0], "write_ms": self.probe["write_ms"][0],
                                    "frac": r["frac"] * r["avg_launch_ms"] / self.probe["write_ms"][0],
                                    "note": "candidate 0 of the probe: what a caller gets without pickStackBuffer (same loop, probe's clock)"}
-        r["workgroup_shares"] = {"xcd_bias": int(self.envs._L.tq_get_xcd_bias()) if self.envs.size >= 7 and self.tdtype != self.torch.uint8 else 0,
+        r["workgroup_shares"] = {"xcd_bias": int(self.envs._L.tq_env_get_xcd_bias(self.envs._h)) if self.envs.size >= 7 and self.tdtype != self.torch.uint8 else 0,
                                  "note": "of every pair of the write's workgroups the one on the even XCD takes 32 + bias, the other 32 - bias of "
                                          "the pair's 64 fine parts of the stack (include/toricenv.h: tq_set_xcd_bias; 0 = equal shares; d <= 5 and u8 stacks: always 0)"}
         if self.probe is not None and "xcd_bias" in self.probe:

@@ -110,11 +110,14 @@ int tq_stack_free(void* ptr);
  * box and buffer measured: profiles/r04_workgroup_end_times.txt), so of every pair of workgroups the even one takes
  * 32 + bias and the odd one 32 - bias of the pair's 64 fine parts -- for d >= 7, f32 / f16 / bf16 stacks of 64 MB and more
  * (smaller lattices and the u8 stack are bound by the producers, not by the stores: there unequal shares only cost).  Default 5 (or the
- * environment variable TORICENV_XCD_BIAS, read once); 0 = equal shares; process-wide; changes the speed of
- * tq_persp_write*, never its result.  EnvSet.pickStackBuffer checks the setting against equal shares on the caller's
- * own write. */
+ * environment variable TORICENV_XCD_BIAS, read once); 0 = equal shares; changes the speed of tq_persp_write*, never
+ * its result.  tq_set_xcd_bias is the process-wide setting, tq_env_set_xcd_bias one handle's own (-1 = follow the
+ * process-wide one, the default).  EnvSet.pickStackBuffer times the caller's own write both ways and sets the HANDLE
+ * to the faster. */
 int tq_set_xcd_bias(int bias);   /* 0..16, else TQ_E_INVALID */
 int tq_get_xcd_bias(void);
+int tq_env_set_xcd_bias(tq_env* h, int bias);   /* -1..16 */
+int tq_env_get_xcd_bias(const tq_env* h);       /* the setting in force for this handle */
 
 int tq_num_envs(const tq_env* h);
 int tq_size(const tq_env* h);

@@ -74,6 +74,7 @@ def test_workgroup_share_setting_is_range_checked(lib):
         for b in (-1, 17, 1 << 20):
             assert lib.tq_set_xcd_bias(b) < 0 and b"xcd bias" in lib.tq_last_error()
             assert lib.tq_get_xcd_bias() == 5
+        assert lib.tq_env_set_xcd_bias(None, 3) < 0 and lib.tq_env_get_xcd_bias(None) < 0      # no handle without a device
     finally:
         lib.tq_set_xcd_bias(before)
 

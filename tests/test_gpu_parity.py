@@ -1120,6 +1120,14 @@ def test_unequal_workgroup_shares_write_the_same_stack(T, d, n, dtype):
             want = torch.as_tensor(cper[i:i + step], device=gpu.device)
             assert torch.equal(out[0][0][:P][i:i + step].to(torch.float32), want.to(torch.float32))
         assert L.tq_set_xcd_bias(17) < 0 and L.tq_set_xcd_bias(-1) < 0 and L.tq_get_xcd_bias() == 3
+        # one handle's own setting goes before the process-wide one; -1 follows it again
+        h = gpu._h
+        assert L.tq_env_get_xcd_bias(h) == 3 and L.tq_env_set_xcd_bias(h, 9) == 0 and L.tq_env_get_xcd_bias(h) == 9 and L.tq_get_xcd_bias() == 3
+        stack9 = torch.full_like(out[0][0], 7)
+        gpu.writePerspectives(stack9, None, offsets)
+        gpu.check()
+        assert torch.equal(stack9, out[0][0])
+        assert L.tq_env_set_xcd_bias(h, 17) < 0 and L.tq_env_set_xcd_bias(h, -2) < 0 and L.tq_env_set_xcd_bias(h, -1) == 0 and L.tq_env_get_xcd_bias(h) == 3
         if d == 7:
             # the probe: candidates of ONE kind write at one rate -> the search is extended once, the first ones still allocated;
             # the share setting is checked on the kept buffer (and whatever it decides, the stack is the same)
@@ -1128,7 +1136,8 @@ def test_unequal_workgroup_shares_write_the_same_stack(T, d, n, dtype):
             added = rep["candidates_added_because_uniform"]
             assert added in (0, 3) and rep["candidates"] == 3 + added == len(rep["write_ms"]) == len(rep["kinds"])
             assert (added == 3) == (min(rep["write_ms"][:3]) > 0.93 * rep["write_ms"][0] and rep["write_ms"][0] >= 0.1)
-            assert "xcd_bias" in rep and rep["xcd_bias"]["bias"] in (0, T.configured_xcd_bias())
+            assert "xcd_bias" in rep and rep["xcd_bias"]["bias"] in (0, default) and L.tq_get_xcd_bias() == default   # the process-wide setting is left alone
+            assert L.tq_env_get_xcd_bias(h) == rep["xcd_bias"]["bias"]
             gpu.writePerspectives(best, None, offsets)
             gpu.check()
             assert torch.equal(best[:P], out[0][0][:P])

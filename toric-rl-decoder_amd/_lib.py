@@ -29,6 +29,8 @@ SYMBOLS = [
     ("tq_stack_free", _i, [_vp]),
     ("tq_set_xcd_bias", _i, [_i]),
     ("tq_get_xcd_bias", _i, []),
+    ("tq_env_set_xcd_bias", _i, [_vp, _i]),
+    ("tq_env_get_xcd_bias", _i, [_vp]),
     ("tq_num_envs", _i, [_vp]),
     ("tq_size", _i, [_vp]),
     ("tq_reset_all", _i, [_vp, _vp, _vp]),

@@ -188,14 +188,14 @@ struct StreamCfg {
 template <int D, typename OutT>
 int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                          int64_t capacity, int* err, hipStream_t stream, int64_t first, int64_t count,
-                         const int32_t* split, unsigned int* slots) {
+                         const int32_t* split, unsigned int* slots, int bias) {
     using C = StreamCfg<D, (int)sizeof(OutT)>;
     // a workgroup's part of the stack is addressed with 32-bit element offsets
     if ((double)count * (2.0 * D * D) * (2.0 * D * D) / SPLIT_MAX * 1.5 > 2.0e9)    // (the largest share is 1.5 of the mean)
         return fail(TQ_E_INVALID, "lattice range too large for one stack write (%lld lattices of d=%d)", (long long)count, D);
     hipLaunchKernelGGL((tq::k_persp_stream<D, OutT, C::NS, C::NP, C::CPW, C::RB, C::RP, false, C::NPW>), dim3(SPLIT_MAX),
                        dim3(64 * (C::NS + C::NPW + C::NP)), 0, stream, vp, n, offsets, (OutT*)out, pos, capacity, err, first, first + count, split,
-                       SPLIT_LG, (D >= 7 && sizeof(OutT) >= 2) ? xcd_bias() : 0, slots, (unsigned long long*)nullptr);
+                       SPLIT_LG, (D >= 7 && sizeof(OutT) >= 2) ? bias : 0, slots, (unsigned long long*)nullptr);
     KCHECK();
     return TQ_OK;
 }
@@ -205,13 +205,13 @@ int launch_persp_write_t(const uint64_t* vp, int64_t n, const int64_t* offsets, 
 template <int D>
 int launch_persp_write(const uint64_t* vp, int64_t n, const int64_t* offsets, void* out, int32_t* pos,
                        int64_t capacity, int dtype, int* err, hipStream_t stream, int64_t first, int64_t count,
-                       const int32_t* split, unsigned int* slots = nullptr) {
+                       const int32_t* split, unsigned int* slots = nullptr, int bias = 0) {
     if (count == 0) return TQ_OK;
     switch (dtype) {
-        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots);
-        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots);
-        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots);
-        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots);
+        case TQ_F32: return launch_persp_write_t<D, float>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots, bias);
+        case TQ_F16: return launch_persp_write_t<D, __half>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots, bias);
+        case TQ_BF16: return launch_persp_write_t<D, tq::bf16_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots, bias);
+        case TQ_U8: return launch_persp_write_t<D, uint8_t>(vp, n, offsets, out, pos, capacity, err, stream, first, count, split, slots, bias);
         default: return fail(TQ_E_INVALID, "unknown dtype %d", dtype);
     }
 }
@@ -247,6 +247,7 @@ struct tq_env {
     int split_last;        // array each belongs to, and which one was written last
     unsigned int* slots;   // N_SLOT_SETS sets of STREAM_SLOT_WORDS counters: the workgroups of a stack write take their shares by XCD (stream_write.hpp)
     unsigned write_seq;    // and leave them zero; write i uses set i % N, so N writes of one handle may be in flight
+    int xcd_bias;          // this handle's share setting (tq_env_set_xcd_bias), or -1: the process-wide one
 };
 
 namespace {
@@ -285,6 +286,13 @@ int tq_set_xcd_bias(int bias) {
     return TQ_OK;
 }
 int tq_get_xcd_bias(void) { return xcd_bias(); }
+int tq_env_set_xcd_bias(tq_env* h, int bias) {
+    if (!h) return fail(TQ_E_INVALID, "NULL handle");
+    if (bias < -1 || bias > 16) return fail(TQ_E_INVALID, "xcd bias %d outside -1..16", bias);
+    h->xcd_bias = bias;
+    return TQ_OK;
+}
+int tq_env_get_xcd_bias(const tq_env* h) { return !h ? TQ_E_INVALID : (h->xcd_bias >= 0 ? h->xcd_bias : xcd_bias()); }
 
 // ---- stack buffers backed by 2 MiB physical chunks (HIP virtual memory API)
 namespace {
@@ -437,6 +445,7 @@ int tq_create(tq_env** out, int n_envs, int d, int device, uint64_t seed, int64_
     h->n = n_envs; h->d = d; h->w = (d * d + 63) / 64; h->device = device;
     h->seed = seed; h->first_env = first_env_id;
     h->terminal_reward = 100.0; h->max_steps = 75;
+    h->xcd_bias = -1;
     h->sched = tq::PerrSchedule{TQ_PERR_FIXED, 0.1, 0.1, 0.1, 0.0};
     const size_t N = (size_t)n_envs, W = (size_t)h->w;
     hipError_t e = hipSuccess;
@@ -672,7 +681,7 @@ int tq_persp_write_range(tq_env* h, const int64_t* offsets, int first, int count
     }
     unsigned int* slots = h->slots + tq::STREAM_SLOT_WORDS * (h->write_seq++ % N_SLOT_SETS);
 #define CALL(D) if (int rc = launch_persp_write<D>(vp, h->n, offsets, out, positions, capacity, dtype, h->err, stream, first, count, \
-        split, slots)) return rc
+        split, slots, h->xcd_bias >= 0 ? h->xcd_bias : xcd_bias())) return rc
     DISPATCH_D(h->d, CALL)
 #undef CALL
     return TQ_OK;

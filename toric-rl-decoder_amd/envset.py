@@ -228,23 +228,15 @@ def to_structured(unpacked, size):
     return rec
 
 
-_CONFIGURED_XCD_BIAS = None
-
-
 def configured_xcd_bias():
-    """The workgroup-share setting this process was started with (toricenv.h: tq_set_xcd_bias; the library's default or
-    TORICENV_XCD_BIAS), whatever pickStackBuffer's checks have left in force since."""
-    global _CONFIGURED_XCD_BIAS
-    if _CONFIGURED_XCD_BIAS is None:
-        _CONFIGURED_XCD_BIAS = int(_lib.load().tq_get_xcd_bias())
-    return _CONFIGURED_XCD_BIAS
+    """The process-wide workgroup-share setting (toricenv.h: tq_set_xcd_bias; the library's default or TORICENV_XCD_BIAS).
+    pickStackBuffer's check decides per EnvSet (tq_env_set_xcd_bias) and leaves this alone."""
+    return int(_lib.load().tq_get_xcd_bias())
 
 
 def set_xcd_bias(bias):
-    """tq_set_xcd_bias for this process, remembered as the configured value (pickStackBuffer checks THAT against equal shares)."""
-    global _CONFIGURED_XCD_BIAS
+    """tq_set_xcd_bias for this process."""
     check(_lib.load().tq_set_xcd_bias(int(bias)))
-    _CONFIGURED_XCD_BIAS = int(bias)
 
 
 class EnvSet:
@@ -269,7 +261,6 @@ class EnvSet:
         self.terminal_reward = float(getattr(env, "terminal_reward", 100.0))
         self.max_steps_per_episode = int(max_steps_per_episode)
         self._L = _lib.load()
-        configured_xcd_bias()                                    # (recorded before any probe of this process changes it)
         with torch.cuda.device(self.device):
             check(self._L.tq_create(C.byref(self._h), self.no_envs, self.size, self.device.index,
                                     C.c_uint64(self.seed & 0xFFFFFFFFFFFFFFFF), self.first_env_id))
@@ -551,18 +542,17 @@ class EnvSet:
                   "addresses": [hex(x.data_ptr()) for x in keep]}
         # The shares of the write's workgroups (tq_set_xcd_bias: the even XCDs' workgroups take more of the stack) against
         # equal shares, on the buffer that was kept: the setting rests on a measured asymmetry of MI355X, so it is checked
-        # where it is used.  Process-wide; d <= 5 never uses it.
+        # where it is used.  The outcome is set on this EnvSet's handle only; d <= 5 and u8 stacks never use unequal shares.
         if check_shares and d >= 7 and dtype != torch.uint8:
             L = self._L
-            b0 = configured_xcd_bias()                          # not tq_get_xcd_bias(): an earlier probe of this process may have switched it off
+            b0 = int(L.tq_get_xcd_bias())                       # the process-wide setting; the decision is this HANDLE's own
             if b0 > 0:
-                L.tq_set_xcd_bias(0)
+                check(L.tq_env_set_xcd_bias(self._h, 0))
                 eq = float(np.median(list(timer(best, per_pass)) + list(timer(best, per_pass))))
-                L.tq_set_xcd_bias(b0)
+                check(L.tq_env_set_xcd_bias(self._h, b0))
                 un = float(np.median(list(timer(best, per_pass)) + list(timer(best, per_pass))))
                 keep_bias = un <= eq
-                if not keep_bias:
-                    L.tq_set_xcd_bias(0)
+                check(L.tq_env_set_xcd_bias(self._h, -1 if keep_bias else 0))
                 report["xcd_bias"] = {"bias": b0 if keep_bias else 0, "write_ms_biased": un, "write_ms_equal_shares": eq}
                 report["probe_ms_chosen"] = min(un, eq)
             else:

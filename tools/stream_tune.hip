@@ -142,7 +142,7 @@ void one(Ctx& c, bool stats, bool is_ref) {
         for (int g = 0; g < 256; ++g) for (int w = w0; w < w1; ++w) {
             const unsigned long long* o = &h[((size_t)g * WV + w) * 4];
             if (!o[0]) continue;
-            tot += o[0]; wa += o[1]; items += (double)(o[3] & 0xFFFFFFFFull); mx = std::max(mx, (double)o[0]); ++n;
+            tot += o[0]; wa += o[1]; items += (double)(o[3] & 0xFFFFull); mx = std::max(mx, (double)o[0]); ++n;
         }
         if (n) printf("      %-10s waves %5d  alive %9.0f cyc (max %9.0f)  waiting for %s %5.1f %%  %s %5.1f %%  items/wave %7.1f  busy cyc/item %7.0f\n",
                       role, n, tot / n, mx, a_name, 100 * wa / tot, b_name, 100 * wb / tot, items / n, (tot - wa - wb) / std::max(1.0, items));
@@ -174,10 +174,19 @@ void one(Ctx& c, bool stats, bool is_ref) {
             double mn = 1e9, mx = 0, sum = 0; int n = 0;
             for (int g = 0; g < 256; ++g) {
                 double f = 1e9;
-                for (int w = 0; w < NS; ++w) { const unsigned long long x = h[((size_t)g * WV + w) * 4 + 3] >> 32; if (x) f = std::min(f, (double)x / 100.0); }
+                for (int w = 0; w < NS; ++w) { const unsigned long long x = h[((size_t)g * WV + w) * 4 + 3] >> 16; if (x) f = std::min(f, (double)x / 100.0); }
                 if (f < 1e9) { mn = std::min(mn, f); mx = std::max(mx, f); sum += f; ++n; }
             }
             if (n) printf("\n      first trip of a workgroup's storers begins after: min %.1f  mean %.1f  max %.1f us", mn, sum / n, mx);
+        }
+        {   // the start of a launch as producer 0 of every workgroup sees it (us after the workgroup began, means)
+            double a = 0, b = 0, c2 = 0; int n = 0;
+            for (int g = 0; g < 256; ++g) {
+                const unsigned long long x = h[((size_t)g * WV + NS + NPW) * 4 + 3] >> 16;
+                if (!(x >> 32)) continue;
+                a += (double)(x & 0xFFFF) / 100.0; b += (double)((x >> 16) & 0xFFFF) / 100.0; c2 += (double)((x >> 32) & 0xFFFF) / 100.0; ++n;
+            }
+            if (n) printf("\n      producer 0: range known after %.1f us, first lattice loaded after %.1f us, in the ring after %.1f us", a / n, b / n, c2 / n);
         }
         printf("\n      mean end by position in the stack (32 consecutive workgroups each):");
         for (int x = 0; x < 8; ++x) { double m = 0; for (int g = 32 * x; g < 32 * x + 32; ++g) m += en[g] / 32; printf(" %.1f", m); }

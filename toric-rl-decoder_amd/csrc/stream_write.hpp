@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
         if (STATS && ln == 0) {                              // o[2]: the wave's life on the constant 100 MHz clock, begin << 32 | end
             unsigned long long* o = stats + ((size_t)blockIdx.x * (NS + NPW + NP) + wv) * 4;
             o[0] = __builtin_readcyclecounter() - t_begin; o[1] = t_a;
-            o[2] = (t_rt << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull); o[3] = n_items | (t_first << 32);   // (storers: + when the first trip began, 10 ns units)
+            o[2] = (t_rt << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull); o[3] = (n_items & 0xFFFFull) | (t_first << 16);   // (+ storers: when the first trip began; producers: three stamps of the start; 10 ns units)
         }
     };
     using Enc = OutEnc<OutT>;
@@ -448,6 +448,7 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
 
     // =============================================================== producer
     const int p = wave - NS - NPW;
+    if (STATS) t_first = (__builtin_amdgcn_s_memrealtime() - t_rt) & 0xFFFFull;       // (producers: when the range was known, 10 ns units ...)
     ProdTables<D, QS>& PT = S.tab[p];
     if (lane < D) {                                          // column masks: the same for every lattice
         const B m = L::lowcols(lane);
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
             if (n == 0) continue;
             const uint32_t q0 = (uint32_t)((int64_t)readlane64((uint64_t)oo, j) - Q0);
             const uint32_t bit0 = head + q0 * (uint32_t)NQ;
-            if (STATS) ++n_items;
+            if (STATS) { if (!n_items) t_first |= ((__builtin_amdgcn_s_memrealtime() - t_rt) & 0xFFFFull) << 16; ++n_items; }   // (... when its first lattice was loaded ...)
             if (QS > 1) {
                 // ---- hit queue: a table slot (the oldest lattices give theirs back as their hits get done; if all are taken
                 // the waiting hits are done now, in a short pass), ring room for the whole lattice -- this wave WAITS only
@@ -635,6 +636,7 @@ __global__ __launch_bounds__(64 * (NS + NPW + NP)) void k_persp_stream(const uin
                 emit_hit(T, k, q0 + (uint32_t)k);
             }
             wave_lds_sync();                                 // T is rewritten by the next lattice
+            if (STATS && n_items == 1 && !(t_first >> 32)) t_first |= ((__builtin_amdgcn_s_memrealtime() - t_rt) & 0xFFFFull) << 32;   // (... and in the ring)
         }
         if (cnt < 64) break;
     }

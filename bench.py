@@ -366,6 +366,28 @@ class ExploreLeg:
                 self.probe["probe_ms_chosen"] = rep["probe_ms_chosen"]
                 ms = self.loop.time_writes(self.stack, 4, skip=1)
                 out["warm_write_ms_after_reprobe"] = float(np.mean(ms))
+        # Nothing else may be keeping the GPU's front end busy when the timed region starts: right after device memory is freed
+        # the driver wipes it, and for that long (45 ms for 120 GB, tools/free_aftermath.py) kernels are dispatched late -- the
+        # writes keep their rate, the gaps between them grow.  One flush window at a time is held against the probe's figure
+        # until it passes (or 2 s are over); what was seen is reported.
+        if self.probe is not None:
+            quiet = {"windows": 0, "waited_ms": 0.0}
+            for _ in range(40):
+                self.loop.drain()
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(self.flush):
+                    self.loop.step()
+                self.loop.drain()
+                torch.cuda.synchronize(self.device)
+                per_step = 1e3 * (time.perf_counter() - t0) / self.flush
+                quiet["windows"] += 1
+                quiet["last_window_ms_per_step"] = per_step
+                if per_step <= 1.15 * self.probe["probe_ms_chosen"] * self.chunks + 0.03:
+                    break
+                time.sleep(0.05)
+                quiet["waited_ms"] += 50.0
+            out["quiet_check"] = quiet
         while self.loop.t % self.flush:         # the timed region starts on a block boundary: every rank flushes (and gathers) at the
             self.loop.step()                    # same steps of it, however many passes its probe and its re-probe took
         self.loop.drain()

@@ -111,3 +111,36 @@ def test_shard_ranges_partition(total, world):
     assert spans[0][0] == 0 and sum(c for _, c in spans) == total
     assert all(f0 + c0 == f1 for (f0, c0), (f1, _) in zip(spans, spans[1:]))
     assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+@settings(max_examples=60, deadline=None)
+@given(bias=st.integers(0, 16), seed=st.integers(0, 2**31 - 1), irregular=st.integers(0, 40))
+def test_workgroup_shares_cover_the_fine_parts_whatever_the_dispatch(bias, seed, irregular):
+    """csrc/stream_write.hpp, "this workgroup's range": 256 workgroups, 128 large slots of 32 + bias fine parts and 128
+    small ones of 32 - bias; a workgroup on an even XCD takes the next large slot, one on an odd XCD the next small
+    one, a kind that has run out sends it to the other kind.  Whatever XCDs the dispatcher puts the workgroups on
+    (round-robin from any start, or `irregular` of them anywhere) and in whatever order their atomics arrive, the
+    ranges [f_lo, f_hi) are a partition of the 8192 fine parts."""
+    rng = np.random.default_rng(seed)
+    G, RR = 256, 32
+    start = int(rng.integers(0, 8))
+    xcd = (start + np.arange(G)) % 8
+    if irregular:
+        xcd[rng.choice(G, irregular, replace=False)] = rng.integers(0, 8, irregular)
+    counters = [0, 0]                                        # slots[large], as in the kernel: index 1 = large
+    covered = np.zeros(G * RR, np.int32)
+    for b in rng.permutation(G):                             # arrival order of the workgroups' atomics
+        large = int(xcd[b] % 2 == 0)
+        t = counters[large]
+        counters[large] += 1
+        if t >= G // 2:
+            large ^= 1
+            t = counters[large]
+            counters[large] += 1
+        assert t < G // 2
+        f_lo = t * 2 * RR + (0 if large else RR + bias)
+        f_hi = f_lo + (RR + bias if large else RR - bias)
+        covered[f_lo:f_hi] += 1
+    assert (covered == 1).all()
+    if not irregular:                                        # round-robin: exactly the even XCDs' workgroups hold the large slots
+        assert counters == [G // 2, G // 2]
